@@ -1,0 +1,454 @@
+// Fused (flash-style) multi-head attention for gfx950: forward, dK/dV backward, dQ backward.
+//
+// Layout: q/k/v/o and their gradients are token-major [B][N][H*D] bf16 (exactly what the projection
+// GEMMs write), addressed with a row stride, so no head permute is ever materialised.  The N x Nk
+// score matrix never reaches HBM: K/V tiles are staged in LDS and scores live in MFMA accumulators.
+//
+// MFMA orientation (v_mfma_f32_32x32x16_bf16): the forward and the dQ pass compute S^T = K Q^T so a
+// lane owns one query column - the softmax row statistics are lane-local plus one exchange with
+// lane^32 - and the accumulator registers 8s..8s+7 are directly the B operand of the following
+// O^T += V^T P^T product (V^T fragments come from ds_read_b64_tr_b16 on the row-major V tile).
+// The dK/dV pass computes S = Q K^T (key on the lane) so P and dS are directly the B operands of
+// dV^T += dO^T P and dK^T += Q^T dS.  Head dims 40/80/160 are zero-padded to 48/80/160 in LDS only.
+// Row statistics (log-sum-exp) are stored in log2 units: lse2 = log2(sum_k exp(scale * q.k)).
+#include "common.h"
+
+struct AttnArgs {
+    const bf16_t *q, *k, *v, *o, *dout;
+    bf16_t *out, *dq, *dk, *dv;
+    float* lse;            // [B][H][Nq]
+    float* delta;          // [B][H][Nq]
+    int B, H, Nq, Nk, D;
+    int ldq, ldk, ldv, ldo;
+    float scale_log2;      // softmax scale * log2(e)
+    float scale;
+};
+
+#define LDS_TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr))
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
+// Row stride (bytes) of a tile that is read with transposing reads of 32-column blocks: the 4 rows a
+// 16-lane group touches must sit 64 B apart modulo the 256 B bank row.
+__host__ __device__ constexpr int tr_ld(int no) { return (no * 64) % 128 == 64 ? no * 64 : no * 64 + 64; }
+
+// Cooperative copy of `nrows` x `ncols8` 16-byte chunks into LDS; rows >= rows_valid and columns >= D
+// are zero filled.
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int rows_valid, int D, char* dst,
+                                           int dst_ld, int nrows, int ncols8) {
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int idx = threadIdx.x; idx < nrows * ncols8; idx += blockDim.x) {
+        const int r = idx / ncols8, c = idx - r * ncols8;
+        bf16x8 v = zero8;
+        if (r < rows_valid && c * 8 < D) v = *(const bf16x8*)(src + (size_t)r * ld + c * 8);
+        *(bf16x8*)(dst + r * dst_ld + c * 16) = v;
+    }
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <int ND, int NO>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    constexpr int DP = 16 * ND;
+    constexpr int KLD = DP * 2 + 16;
+    constexpr int VLD = tr_ld(NO);
+    __shared__ __attribute__((aligned(16))) char smem[64 * KLD + 64 * VLD];
+    char* Ks = smem;
+    char* Vs = smem + 64 * KLD;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bf16_t* Qb = p.q + (size_t)b * p.Nq * p.ldq + h * p.D;
+    const bf16_t* Kb = p.k + (size_t)b * p.Nk * p.ldk + h * p.D;
+    const bf16_t* Vb = p.v + (size_t)b * p.Nk * p.ldv + h * p.D;
+
+    const int qrow = q0 + l31;
+    const bool q_ok = qrow < p.Nq;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 qf[ND];
+#pragma unroll
+    for (int ks = 0; ks < ND; ++ks) {
+        const int d = ks * 16 + 8 * hh;
+        qf[ks] = (q_ok && d < p.D) ? *(const bf16x8*)(Qb + (size_t)qrow * p.ldq + d) : zero8;
+    }
+    f32x16 o[NO];
+#pragma unroll
+    for (int i = 0; i < NO; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    const int nkt = (p.Nk + 63) / 64;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 64;
+        __syncthreads();
+        stage_tile(Kb + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, p.D, Ks, KLD, 64, DP / 8);
+        stage_tile(Vb + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, p.D, Vs, VLD, 64, NO * 4);
+        __syncthreads();
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < ND; ++ks) {
+                const bf16x8 a = *(const bf16x8*)(Ks + (kb * 32 + l31) * KLD + (ks * 16 + 8 * hh) * 2);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = s[kb][r] * p.scale_log2;
+                if (key >= p.Nk) v = -INFINITY;
+                s[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = exp2f(m - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(s[kb][r] - m_new);
+                s[kb][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        l = l * alpha + sum;
+        m = m_new;
+#pragma unroll
+        for (int i = 0; i < NO; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[kb][st][j] = (bf16_t)s[kb][8 * st + j];
+
+        const int tr_row = 4 * hh + ((lane & 15) >> 2);
+        const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+#pragma unroll
+        for (int db = 0; db < NO; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const char* a0 = Vs + (kb * 32 + 16 * st + tr_row) * VLD + db * 64 + tr_col;
+                    const bf16x8 a = cat4(LDS_TR(a0), LDS_TR(a0 + 8 * VLD));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[kb][st], o[db], 0, 0, 0);
+                }
+    }
+
+    if (q_ok) {
+        const float inv = 1.f / l;
+        bf16_t* Ob = p.out + ((size_t)b * p.Nq + qrow) * p.ldo + h * p.D;
+#pragma unroll
+        for (int db = 0; db < NO; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * hh;
+                if (d < p.D) {
+                    bf16x4 ov = {(bf16_t)(o[db][4 * g] * inv), (bf16_t)(o[db][4 * g + 1] * inv),
+                                 (bf16_t)(o[db][4 * g + 2] * inv), (bf16_t)(o[db][4 * g + 3] * inv)};
+                    *(bf16x4*)(Ob + d) = ov;
+                }
+            }
+        if (hh == 0 && p.lse) p.lse[((size_t)b * p.H + h) * p.Nq + qrow] = m + log2f(l);
+    }
+}
+
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+__global__ void attn_delta_kernel(const AttnArgs p) {
+    const size_t total = (size_t)p.B * p.Nq * p.H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % p.H);
+        const size_t row = i / p.H;      // b*Nq + q
+        const bf16_t* o = p.o + row * p.ldo + h * p.D;
+        const bf16_t* g = p.dout + row * p.ldo + h * p.D;
+        float s = 0.f;
+        for (int d = 0; d < p.D; d += 8) {
+            const bf16x8 a = *(const bf16x8*)(o + d), c = *(const bf16x8*)(g + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
+        }
+        const size_t bq = row / p.Nq, q = row - bq * p.Nq;
+        p.delta[(bq * p.H + h) * p.Nq + q] = s;
+    }
+}
+
+// =============================================================================================
+// backward: dK, dV.  Workgroup = 128 keys of one (b,h) (32 per wave); loops over 32-query tiles.
+// =============================================================================================
+template <int ND, int NO>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p) {
+    constexpr int TLD = tr_ld(NO);      // Q / dO tiles [32][NO*32], row + transposed reads
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * TLD + 64 * 4];
+    char* Qs = smem;
+    char* Gs = smem + 32 * TLD;
+    float* Ls = (float*)(smem + 2 * 32 * TLD);   // lse2[32], delta[32]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int key = blockIdx.x * 128 + wave * 32 + l31;
+    const bool k_ok = key < p.Nk;
+    const bf16_t* Qb = p.q + (size_t)b * p.Nq * p.ldq + h * p.D;
+    const bf16_t* Gb = p.dout + (size_t)b * p.Nq * p.ldo + h * p.D;
+    const bf16_t* Kb = p.k + (size_t)b * p.Nk * p.ldk + h * p.D;
+    const bf16_t* Vb = p.v + (size_t)b * p.Nk * p.ldv + h * p.D;
+    const float* lse = p.lse + ((size_t)b * p.H + h) * p.Nq;
+    const float* dlt = p.delta + ((size_t)b * p.H + h) * p.Nq;
+
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 kf[ND], vf[ND];
+#pragma unroll
+    for (int ks = 0; ks < ND; ++ks) {
+        const int d = ks * 16 + 8 * hh;
+        const bool ok = k_ok && d < p.D;
+        kf[ks] = ok ? *(const bf16x8*)(Kb + (size_t)key * p.ldk + d) : zero8;
+        vf[ks] = ok ? *(const bf16x8*)(Vb + (size_t)key * p.ldv + d) : zero8;
+    }
+    f32x16 dkT[NO], dvT[NO];
+#pragma unroll
+    for (int i = 0; i < NO; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkT[i][r] = 0.f; dvT[i][r] = 0.f; }
+
+    const int tr_row = 4 * hh + ((lane & 15) >> 2);
+    const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+    const int nqt = (p.Nq + 31) / 32;
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int q0 = qt * 32;
+        __syncthreads();
+        stage_tile(Qb + (size_t)q0 * p.ldq, p.ldq, p.Nq - q0, p.D, Qs, TLD, 32, NO * 4);
+        stage_tile(Gb + (size_t)q0 * p.ldo, p.ldo, p.Nq - q0, p.D, Gs, TLD, 32, NO * 4);
+        if (threadIdx.x < 64) {
+            const int qi = q0 + (threadIdx.x & 31);
+            float v = 0.f;
+            if (qi < p.Nq) v = threadIdx.x < 32 ? lse[qi] : dlt[qi];
+            else if (threadIdx.x < 32) v = INFINITY;     // padded query rows: p = exp2(-inf) = 0
+            Ls[threadIdx.x] = v;
+        }
+        __syncthreads();
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < ND; ++ks) {
+            const int off = l31 * TLD + (ks * 16 + 8 * hh) * 2;
+            const bf16x8 aq = *(const bf16x8*)(Qs + off);
+            const bf16x8 ag = *(const bf16x8*)(Gs + off);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vf[ks], dp, 0, 0, 0);
+        }
+        bf16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float pv = exp2f(s[r] * p.scale_log2 - Ls[qi]);
+            if (!k_ok) pv = 0.f;
+            const float dsv = pv * (dp[r] - Ls[32 + qi]);
+            pf[r >> 3][r & 7] = (bf16_t)pv;
+            dsf[r >> 3][r & 7] = (bf16_t)dsv;
+        }
+#pragma unroll
+        for (int db = 0; db < NO; ++db)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int off = (16 * st + tr_row) * TLD + db * 64 + tr_col;
+                const bf16x8 ag = cat4(LDS_TR(Gs + off), LDS_TR(Gs + off + 8 * TLD));
+                dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, pf[st], dvT[db], 0, 0, 0);
+                const bf16x8 aq = cat4(LDS_TR(Qs + off), LDS_TR(Qs + off + 8 * TLD));
+                dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, dsf[st], dkT[db], 0, 0, 0);
+            }
+    }
+    if (k_ok) {
+        bf16_t* dK = p.dk + ((size_t)b * p.Nk + key) * p.ldk + h * p.D;
+        bf16_t* dV = p.dv + ((size_t)b * p.Nk + key) * p.ldv + h * p.D;
+#pragma unroll
+        for (int db = 0; db < NO; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * hh;
+                if (d < p.D) {
+                    bf16x4 a = {(bf16_t)(dkT[db][4 * g] * p.scale), (bf16_t)(dkT[db][4 * g + 1] * p.scale),
+                                (bf16_t)(dkT[db][4 * g + 2] * p.scale), (bf16_t)(dkT[db][4 * g + 3] * p.scale)};
+                    bf16x4 c = {(bf16_t)dvT[db][4 * g], (bf16_t)dvT[db][4 * g + 1], (bf16_t)dvT[db][4 * g + 2],
+                                (bf16_t)dvT[db][4 * g + 3]};
+                    *(bf16x4*)(dK + d) = a;
+                    *(bf16x4*)(dV + d) = c;
+                }
+            }
+    }
+}
+
+// =============================================================================================
+// backward: dQ.  Workgroup = 128 queries of one (b,h) (32 per wave); loops over 64-key tiles.
+// =============================================================================================
+template <int ND, int NO>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
+    constexpr int DP = 16 * ND;
+    constexpr int KLD = tr_ld(NO);        // K tile: row reads (S^T) + transposed reads (dQ^T)
+    constexpr int VLD = DP * 2 + 16;      // V tile: row reads only
+    __shared__ __attribute__((aligned(16))) char smem[64 * KLD + 64 * VLD];
+    char* Ks = smem;
+    char* Vs = smem + 64 * KLD;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_ok = qrow < p.Nq;
+    const bf16_t* Qb = p.q + (size_t)b * p.Nq * p.ldq + h * p.D;
+    const bf16_t* Gb = p.dout + (size_t)b * p.Nq * p.ldo + h * p.D;
+    const bf16_t* Kb = p.k + (size_t)b * p.Nk * p.ldk + h * p.D;
+    const bf16_t* Vb = p.v + (size_t)b * p.Nk * p.ldv + h * p.D;
+
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 qf[ND], gf[ND];
+#pragma unroll
+    for (int ks = 0; ks < ND; ++ks) {
+        const int d = ks * 16 + 8 * hh;
+        const bool ok = q_ok && d < p.D;
+        qf[ks] = ok ? *(const bf16x8*)(Qb + (size_t)qrow * p.ldq + d) : zero8;
+        gf[ks] = ok ? *(const bf16x8*)(Gb + (size_t)qrow * p.ldo + d) : zero8;
+    }
+    const float lse = q_ok ? p.lse[((size_t)b * p.H + h) * p.Nq + qrow] : INFINITY;
+    const float dlt = q_ok ? p.delta[((size_t)b * p.H + h) * p.Nq + qrow] : 0.f;
+    f32x16 dqT[NO];
+#pragma unroll
+    for (int i = 0; i < NO; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqT[i][r] = 0.f;
+
+    const int tr_row = 4 * hh + ((lane & 15) >> 2);
+    const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+    const int nkt = (p.Nk + 63) / 64;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 64;
+        __syncthreads();
+        stage_tile(Kb + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, p.D, Ks, KLD, 64, NO * 4);
+        stage_tile(Vb + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, p.D, Vs, VLD, 64, DP / 8);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < ND; ++ks) {
+                const bf16x8 ak = *(const bf16x8*)(Ks + (kb * 32 + l31) * KLD + (ks * 16 + 8 * hh) * 2);
+                const bf16x8 av = *(const bf16x8*)(Vs + (kb * 32 + l31) * VLD + (ks * 16 + 8 * hh) * 2);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[ks], dp, 0, 0, 0);
+            }
+            bf16x8 dsf[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float pv = exp2f(s[r] * p.scale_log2 - lse);
+                if (key >= p.Nk) pv = 0.f;
+                dsf[r >> 3][r & 7] = (bf16_t)(pv * (dp[r] - dlt));
+            }
+#pragma unroll
+            for (int db = 0; db < NO; ++db)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int off = (kb * 32 + 16 * st + tr_row) * KLD + db * 64 + tr_col;
+                    const bf16x8 a = cat4(LDS_TR(Ks + off), LDS_TR(Ks + off + 8 * KLD));
+                    dqT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsf[st], dqT[db], 0, 0, 0);
+                }
+        }
+    }
+    if (q_ok) {
+        bf16_t* dQ = p.dq + ((size_t)b * p.Nq + qrow) * p.ldq + h * p.D;
+#pragma unroll
+        for (int db = 0; db < NO; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * hh;
+                if (d < p.D) {
+                    bf16x4 a = {(bf16_t)(dqT[db][4 * g] * p.scale), (bf16_t)(dqT[db][4 * g + 1] * p.scale),
+                                (bf16_t)(dqT[db][4 * g + 2] * p.scale), (bf16_t)(dqT[db][4 * g + 3] * p.scale)};
+                    *(bf16x4*)(dQ + d) = a;
+                }
+            }
+    }
+}
+
+template <int ND, int NO>
+static int launch_fwd(const AttnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((attn_fwd_kernel<ND, NO>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    return mi355_check_launch("attn_fwd");
+}
+template <int ND, int NO>
+static int launch_bwd(const AttnArgs& a, hipStream_t s) {
+    const size_t total = (size_t)a.B * a.Nq * a.H;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<ND, NO>), dim3((a.Nk + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<ND, NO>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    return mi355_check_launch("attn_bwd");
+}
+
+static int check_attn(const AttnArgs& a) {
+    if (a.D % 8 || a.D < 8 || a.D > 160) return mi355_fail(MI355_ERR_UNSUPPORTED, "attention: head dim %d (multiple of 8, <= 160)", a.D);
+    if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return mi355_fail(MI355_ERR_ARG, "attention: row strides must be multiples of 8");
+    if (a.Nq <= 0 || a.Nk <= 0 || a.B <= 0 || a.H <= 0) return mi355_fail(MI355_ERR_ARG, "attention: empty problem");
+    if ((long long)a.B * a.H > 65535) return mi355_fail(MI355_ERR_UNSUPPORTED, "attention: B*H > 65535");
+    return 0;
+}
+
+#define ATTN_DISPATCH(FN, a, s)                                          \
+    ((a).D <= 16 ? FN<1, 1>(a, s) : (a).D <= 32 ? FN<2, 1>(a, s)         \
+     : (a).D <= 48 ? FN<3, 2>(a, s) : (a).D <= 64 ? FN<4, 2>(a, s)       \
+     : (a).D <= 80 ? FN<5, 3>(a, s) : (a).D <= 96 ? FN<6, 3>(a, s)       \
+     : (a).D <= 128 ? FN<8, 4>(a, s) : FN<10, 5>(a, s))
+
+extern "C" {
+
+int mi355_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Nq,
+                        int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale, void* stream) {
+    if (!q || !k || !v || !out) return mi355_fail(MI355_ERR_ARG, "attention_fwd: null pointer");
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    if (int rc = check_attn(a)) return rc;
+    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Nq * Nk * D);
+    return ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
+}
+
+// delta: scratch [B][H][Nq] floats.  dq uses ldq, dk ldk, dv ldv, dout/o use ldo.
+int mi355_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                        float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int D, int ldq,
+                        int ldk, int ldv, int ldo, float scale, void* stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv)
+        return mi355_fail(MI355_ERR_ARG, "attention_bwd: null pointer");
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
+    a.dout = (const bf16_t*)dout; a.lse = (float*)lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk;
+    a.dv = (bf16_t*)dv; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    if (int rc = check_attn(a)) return rc;
+    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 14.0 * B * H * (double)Nq * Nk * D);
+    return ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Shared declarations for the gfx950 denoiser kernels (internal; the public C ABI is
+// include/mi355_denoiser.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MI355_OK 0
+#define MI355_ERR_ARG (-1)
+#define MI355_ERR_LAUNCH (-2)
+#define MI355_ERR_UNSUPPORTED (-3)
+
+// Records a message retrievable through mi355_last_error() (thread-local) and returns `code`.
+int mi355_fail(int code, const char* fmt, ...);
+// Checks hipGetLastError() after a launch.
+int mi355_check_launch(const char* what);
+
+// Optional per-family launch timing (HIP events recorded on the launch stream).
+enum { FAM_GEMM = 0, FAM_WGRAD = 1, FAM_ATTN = 2, FAM_NORM = 3, FAM_ELEM = 4, FAM_COUNT = 5 };
+void mi355_prof_begin(int fam, hipStream_t s, double work);  // work = flops (contractions) or bytes
+void mi355_prof_end(int fam, hipStream_t s);
+
+struct ProfScope {
+    int fam; hipStream_t s;
+    ProfScope(int f, hipStream_t st, double work) : fam(f), s(st) { mi355_prof_begin(f, st, work); }
+    ~ProfScope() { mi355_prof_end(fam, s); }
+};
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Sum over the whole workgroup (blockDim.x multiple of 64, <= 1024). `red` holds >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// Blocks that share an XCD (ids congruent mod 8) get one contiguous chunk of the logical grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}

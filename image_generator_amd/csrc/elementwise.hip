@@ -1,0 +1,583 @@
+// HBM-bound elementwise / layout / loss / optimizer kernels (16-byte vector accesses, fp32 math).
+#include "common.h"
+#include <math.h>
+
+#define GRID_FOR(n, per) ({ size_t _g = ((size_t)(n) + (per) - 1) / (per); if (_g > 4096) _g = 4096; if (_g < 1) _g = 1; (int)_g; })
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- GEGLU: in [M][2F] (hidden | gate) -> out [M][F] = hidden * gelu(gate)
+__global__ void geglu_fwd_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, size_t M, int F) {
+    const int nc = F >> 3;
+    const size_t total = M * nc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / nc; const int c = (int)(i - m * nc) * 8;
+        const bf16x8 h = *(const bf16x8*)(in + m * 2 * F + c);
+        const bf16x8 g = *(const bf16x8*)(in + m * 2 * F + F + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)h[e] * gelu_f((float)g[e]));
+        *(bf16x8*)(out + m * F + c) = o;
+    }
+}
+__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ dout,
+                                 bf16_t* __restrict__ din, size_t M, int F) {
+    const int nc = F >> 3;
+    const size_t total = M * nc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / nc; const int c = (int)(i - m * nc) * 8;
+        const bf16x8 h = *(const bf16x8*)(in + m * 2 * F + c);
+        const bf16x8 g = *(const bf16x8*)(in + m * 2 * F + F + c);
+        const bf16x8 d = *(const bf16x8*)(dout + m * F + c);
+        bf16x8 dh, dg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gv = (float)g[e], dv = (float)d[e];
+            dh[e] = (bf16_t)(dv * gelu_f(gv));
+            dg[e] = (bf16_t)(dv * (float)h[e] * gelu_grad_f(gv));
+        }
+        *(bf16x8*)(din + m * 2 * F + c) = dh;
+        *(bf16x8*)(din + m * 2 * F + F + c) = dg;
+    }
+}
+
+// ---- SiLU on small fp32 matrices (timestep-embedding MLP), output bf16 for the next GEMM
+__global__ void silu_f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = (bf16_t)(v / (1.f + __expf(-v)));
+    }
+}
+// dx = dy * silu'(x), fp32
+__global__ void silu_bwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                    size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float s = 1.f / (1.f + __expf(-v));
+        dx[i] = dy[i] * s * (1.f + v * (1.f - s));
+    }
+}
+
+// ---- sinusoidal timestep embedding: out[b][0:half] = cos(t*f_i), out[b][half:] = sin(t*f_i)
+__global__ void timestep_embed_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int B, int dim) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i - b * half;
+    const float f = __expf(-9.210340371976184f * (float)j / (float)half);
+    const float a = t[b] * f;
+    out[(size_t)b * dim + j] = (bf16_t)cosf(a);
+    out[(size_t)b * dim + half + j] = (bf16_t)sinf(a);
+}
+
+// ---- casts and layout
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4*)(x + i * 8), b = *(const f32x4*)(x + i * 8 + 4);
+        bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+        *(bf16x8*)(y + i * 8) = o;
+    }
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+// in: [G][R][C] -> out: [G][C][R]  (32x32 LDS tile transpose), bf16
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int C) {
+    __shared__ bf16_t tile[32][33];
+    const size_t g = blockIdx.z;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? in[(g * R + r) * C + c] : (bf16_t)0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < R && c < C) out[(g * C + c) * R + r] = tile[tx][k];
+    }
+}
+// conv weight for the data gradient: w [Co][T][Ci] -> wt [Ci][T][Co] with the taps reversed (T = 9 or 1)
+__global__ void conv_weight_transpose_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int Co, int T,
+                                             int Ci) {
+    __shared__ bf16_t tile[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int co = co0 + k, ci = ci0 + tx;
+        tile[k][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + tap) * Ci + ci] : (bf16_t)0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int ci = ci0 + k, co = co0 + tx;
+        if (co < Co && ci < Ci) wt[((size_t)ci * T + (T - 1 - tap)) * Co + co] = tile[tx][k];
+    }
+}
+// NCHW fp32 [B][Cs][HW] -> NHWC bf16 [B][HW][Cd] (channels >= Cs zero padded)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int Cs, int Cd, int HW) {
+    const size_t total = (size_t)B * HW * Cd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cd); const size_t p = i / Cd; const int hw = (int)(p % HW); const size_t b = p / HW;
+        y[i] = c < Cs ? (bf16_t)x[(b * Cs + c) * HW + hw] : (bf16_t)0.f;
+    }
+}
+// NHWC fp32 [B][HW][Cs] -> NCHW fp32 [B][Cd][HW] (first Cd channels)
+__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int Cs, int Cd, int HW) {
+    const size_t total = (size_t)B * Cd * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % HW); const size_t p = i / HW; const int c = (int)(p % Cd); const size_t b = p / Cd;
+        y[i] = x[(b * HW + hw) * Cs + c];
+    }
+}
+// gradient of a nearest 2x upsample: dx[b][y][x][c] = sum of the 2x2 block of dy (NHWC bf16, dy is [B][2H][2W][C])
+__global__ void sumpool2x2_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int H, int W, int C) {
+    const int nc = C >> 3;
+    const size_t total = (size_t)B * H * W * nc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nc) * 8; size_t p = i / nc;
+        const int x = (int)(p % W); p /= W; const int y = (int)(p % H); const size_t b = p / H;
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+            for (int dxx = 0; dxx < 2; ++dxx) {
+                const bf16x8 v = *(const bf16x8*)(dy + ((b * 2 * H + 2 * y + dyy) * 2 * W + 2 * x + dxx) * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)a[e];
+        *(bf16x8*)(dx + ((b * H + y) * W + x) * C + c) = o;
+    }
+}
+
+// ---- MSE objective, fused forward + gradient: loss += sum((p-t)^2)/n ; grad = 2(p-t)/n
+__global__ __launch_bounds__(256) void mse_fused_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        float* __restrict__ grad, float* __restrict__ loss, size_t n) {
+    __shared__ float red[16];
+    const float inv = 1.f / (float)n;
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = pred[i] - target[i];
+        s += d * d;
+        if (grad) grad[i] = 2.f * d * inv;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(loss, s * inv);
+}
+
+// ---- diffusion schedule elementwise ops (fp32, NCHW contiguous, per-sample coefficients)
+__global__ void ddpm_add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                      const long long* __restrict__ t, const float* __restrict__ acp,
+                                      float* __restrict__ out, int B, size_t per) {
+    const size_t total = (size_t)B * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = acp[t[i / per]];
+        out[i] = sqrtf(a) * x0[i] + sqrtf(1.f - a) * noise[i];
+    }
+}
+// eps = eps_u + g (eps_c - eps_u);  x_prev = sqrt(a_prev) * (x - sqrt(1-a_t) eps)/sqrt(a_t) + sqrt(1-a_prev) eps
+// coef (device): {a_t, a_prev, guidance}.  eps holds [2][n] (uncond first) when cfg != 0, else [n].
+__global__ void ddim_step_cfg_kernel(const float* __restrict__ eps, const float* __restrict__ x, float* __restrict__ out,
+                                     const float* __restrict__ coef, size_t n, int cfg) {
+    const float a_t = coef[0], a_p = coef[1], g = coef[2];
+    const float st = sqrtf(1.f - a_t), it = rsqrtf(a_t), sp = sqrtf(a_p), np_ = sqrtf(1.f - a_p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float e = eps[i];
+        if (cfg) e = e + g * (eps[n + i] - e);
+        const float x0 = (x[i] - st * e) * it;
+        out[i] = sp * x0 + np_ * e;
+    }
+}
+
+// ---- optimizer: sum of squares, clip coefficient, fused AdamW with bf16 weight refresh
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, size_t n) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(g + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = n4 * 4; i < n; ++i) s += g[i] * g[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+// hyper (device floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=bias_corr1 [6]=bias_corr2
+//                        [7]=max_grad_norm (<=0: no clipping) [8]=grad pre-scale (e.g. 1/world)
+// state (device floats): [0]=sum of squared grads (input) ; [1]=skip flag output (1 when non-finite)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, bf16_t* __restrict__ p_bf16, const float* __restrict__ hyper,
+                             const float* __restrict__ state, size_t n) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6];
+    const float maxn = hyper[7], pre = hyper[8];
+    const float gnorm = sqrtf(state[0]) * pre;
+    if (!(gnorm == gnorm) || gnorm > 3.0e38f) return;          // non-finite gradients: skip the update
+    float scale = pre;
+    if (maxn > 0.f) { const float c = maxn / (gnorm + 1e-6f); if (c < 1.f) scale *= c; }
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 pv = *(f32x4*)(p + i * 4);
+        const f32x4 gv = *(const f32x4*)(g + i * 4);
+        f32x4 mv = *(f32x4*)(m + i * 4), vv = *(f32x4*)(v + i * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gv[e] * scale;
+            pv[e] *= (1.f - lr * wd);
+            mv[e] = b1 * mv[e] + (1.f - b1) * gg;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gg * gg;
+            const float denom = sqrtf(vv[e]) / sqrtf(bc2) + eps;
+            pv[e] -= (lr / bc1) * (mv[e] / denom);
+            o[e] = (bf16_t)pv[e];
+        }
+        *(f32x4*)(p + i * 4) = pv; *(f32x4*)(m + i * 4) = mv; *(f32x4*)(v + i * 4) = vv;
+        if (p_bf16) *(bf16x4*)(p_bf16 + i * 4) = o;
+    }
+}
+
+// ---- symmetric InfoNCE (CLIP-style) on L2-normalised embeddings, one workgroup, B <= 1024
+//   logits = (t_hat . i_hat^T) / clamp(exp(log_temp), 1e-4, 1e4); loss = (CE_rows + CE_cols)/2
+// Outputs loss, d_text, d_image, d_log_temp.  scratch: 4*B*B floats? no: works row-by-row from global logits.
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ xh,
+                                                          float* __restrict__ nrm, int B, int D) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) { const float v = x[(size_t)b * D + d]; s += v * v; }
+    s = block_sum(s, red);
+    const float n = fmaxf(sqrtf(s), 1e-12f);
+    if (threadIdx.x == 0) nrm[b] = n;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) xh[(size_t)b * D + d] = x[(size_t)b * D + d] / n;
+}
+// logits[i][j] = dot(th[i], ih[j]) * inv_temp     (grid = B x B/… small; fp32 exact dot)
+__global__ __launch_bounds__(256) void clip_logits_kernel(const float* __restrict__ th, const float* __restrict__ ih,
+                                                          const float* __restrict__ log_temp, float* __restrict__ logits,
+                                                          int B, int D) {
+    const int i = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float temp = fminf(fmaxf(__expf(log_temp[0]), 1e-4f), 1e4f);
+    for (int j = blockIdx.x * 4 + w; j < B; j += gridDim.x * 4) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += th[(size_t)i * D + d] * ih[(size_t)j * D + d];
+        s = wave_sum(s);
+        if (lane == 0) logits[(size_t)i * B + j] = s / temp;
+    }
+}
+// row (dir=0) / column (dir=1) log-sum-exp of logits
+__global__ __launch_bounds__(256) void clip_lse_kernel(const float* __restrict__ logits, float* __restrict__ lse, int B) {
+    __shared__ float red[16];
+    const int r = blockIdx.x, dir = blockIdx.y;
+    float mx = -3.0e38f;
+    for (int j = threadIdx.x; j < B; j += blockDim.x) mx = fmaxf(mx, dir ? logits[(size_t)j * B + r] : logits[(size_t)r * B + j]);
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) mx = fmaxf(mx, red[k]);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < B; j += blockDim.x) s += __expf((dir ? logits[(size_t)j * B + r] : logits[(size_t)r * B + j]) - mx);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) lse[(size_t)dir * B + r] = mx + logf(s);
+}
+// loss and dlogits (in place):  dL/dlogits[i][j] = ( softmax_row + softmax_col - 2*delta_ij ) / (2B)
+__global__ __launch_bounds__(256) void clip_dlogits_kernel(float* __restrict__ logits, const float* __restrict__ lse,
+                                                           float* __restrict__ loss, float* __restrict__ dlogtemp,
+                                                           int B) {
+    __shared__ float red[16];
+    const int i = blockIdx.x;
+    float acc_t = 0.f, l = 0.f;
+    for (int j = threadIdx.x; j < B; j += blockDim.x) {
+        const float z = logits[(size_t)i * B + j];
+        float d = (__expf(z - lse[i]) + __expf(z - lse[B + j])) * (0.5f / B);
+        if (i == j) { d -= 1.0f / B; l = 0.5f * ((lse[i] - z) + (lse[B + i] - z)) / B; }
+        logits[(size_t)i * B + j] = d;
+        acc_t += d * z;          // d logits / d log_temp = -logits (when the clamp is inactive)
+    }
+    acc_t = block_sum(acc_t, red);
+    l = block_sum(l, red);
+    if (threadIdx.x == 0) { atomicAdd(loss, l); atomicAdd(dlogtemp, -acc_t); }
+}
+// d_xhat[i][:] = sum_j dlogits[i][j] (or [j][i]) * other_hat[j][:] / temp ; then through the L2 normalisation:
+// dx = (d_xhat - xhat * dot(xhat, d_xhat)) / norm
+__global__ __launch_bounds__(256) void clip_dembed_kernel(const float* __restrict__ dlogits, const float* __restrict__ other,
+                                                          const float* __restrict__ xh, const float* __restrict__ nrm,
+                                                          const float* __restrict__ log_temp, float* __restrict__ dx,
+                                                          int B, int D, int transpose) {
+    __shared__ float red[16];
+    extern __shared__ float dxh[];
+    const int i = blockIdx.x;
+    const float temp = fminf(fmaxf(__expf(log_temp[0]), 1e-4f), 1e4f);
+    float dot = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < B; ++j) s += (transpose ? dlogits[(size_t)j * B + i] : dlogits[(size_t)i * B + j]) * other[(size_t)j * D + d];
+        s /= temp;
+        dxh[d] = s;
+        dot += s * xh[(size_t)i * D + d];
+    }
+    dot = block_sum(dot, red);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dx[(size_t)i * D + d] = (dxh[d] - xh[(size_t)i * D + d] * dot) / nrm[i];
+}
+__global__ void clip_temp_clamp_kernel(const float* __restrict__ log_temp, float* __restrict__ dlogtemp) {
+    const float e = __expf(log_temp[0]);
+    if (e < 1e-4f || e > 1e4f) dlogtemp[0] = 0.f;   // clamp saturated: no gradient
+}
+
+// ---- LoRA skinny products
+// t[m][r] = sum_k x[m][k] * A[r][k]     (x bf16 [M][K], A fp32 [R][K], R <= 16), one wave per row
+__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, const float* __restrict__ A,
+                                                        float* __restrict__ t, int M, int K, int R) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const bf16x8 xv = *(const bf16x8*)(x + (size_t)row * K + k);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < R) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)xv[e] * A[(size_t)r * K + k + e];
+                acc[r] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r < R) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0) t[(size_t)row * R + r] = s;
+        }
+    }
+}
+// dt[m][r] = alpha * sum_n dy[m][n] * Bm[n][r]   (dy bf16 [M][N], Bm fp32 [N][R])
+__global__ __launch_bounds__(256) void lora_dt_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ Bm,
+                                                      float* __restrict__ dt, int M, int N, int R, float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int n = lane * 8; n < N; n += 512) {
+        const bf16x8 dv = *(const bf16x8*)(dy + (size_t)row * N + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = (float)dv[e];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r < R) acc[r] += d * Bm[(size_t)(n + e) * R + r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r < R) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0) dt[(size_t)row * R + r] = s * alpha;
+        }
+    }
+}
+// out[c][r] (+)= scale * sum_m y[m][c] * t[m][r]   (y bf16 [M][C], t fp32 [M][R]); out fp32 [C][R] pre-zeroed.
+// Serves dB (y = dy, t = x A^T, scale = alpha) and dA^T (y = x, t = dt, scale = 1).
+__global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restrict__ y, const float* __restrict__ t,
+                                                         float* __restrict__ out, int M, int C, int R, float scale,
+                                                         int rows_per_block, int out_transposed) {
+    const int nc = C >> 3;
+    const int r_begin = blockIdx.x * rows_per_block;
+    int r_end = r_begin + rows_per_block;
+    if (r_end > M) r_end = M;
+    for (int c8 = threadIdx.x; c8 < nc; c8 += blockDim.x) {
+        float acc[8][16];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+        for (int m = r_begin; m < r_end; ++m) {
+            const bf16x8 yv = *(const bf16x8*)(y + (size_t)m * C + c8 * 8);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r < R) {
+                    const float tv = t[(size_t)m * R + r];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e][r] += (float)yv[e] * tv;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r < R) {
+                    float* dst = out_transposed ? out + (size_t)r * C + c8 * 8 + e : out + (size_t)(c8 * 8 + e) * R + r;
+                    atomicAdd(dst, acc[e][r] * scale);
+                }
+            }
+    }
+}
+
+extern "C" {
+
+#define ST ((hipStream_t)stream)
+
+int mi355_geglu_fwd(const void* in, void* out, long long M, int F, void* stream) {
+    if (!in || !out || (F & 7)) return mi355_fail(MI355_ERR_ARG, "geglu_fwd: bad arguments");
+    ProfScope prof(FAM_ELEM, ST, (double)M * F * 2 * 3);
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(GRID_FOR((size_t)M * (F / 8), 256)), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, (size_t)M, F);
+    return mi355_check_launch("geglu_fwd");
+}
+int mi355_geglu_bwd(const void* in, const void* dout, void* din, long long M, int F, void* stream) {
+    if (!in || !dout || !din || (F & 7)) return mi355_fail(MI355_ERR_ARG, "geglu_bwd: bad arguments");
+    ProfScope prof(FAM_ELEM, ST, (double)M * F * 2 * 5);
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(GRID_FOR((size_t)M * (F / 8), 256)), dim3(256), 0, ST, (const bf16_t*)in, (const bf16_t*)dout, (bf16_t*)din, (size_t)M, F);
+    return mi355_check_launch("geglu_bwd");
+}
+int mi355_silu_f32_to_bf16(const float* x, void* y, long long n, void* stream) {
+    if (!x || !y) return mi355_fail(MI355_ERR_ARG, "silu: null pointer");
+    hipLaunchKernelGGL(silu_f32_to_bf16_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, ST, x, (bf16_t*)y, (size_t)n);
+    return mi355_check_launch("silu_f32_to_bf16");
+}
+int mi355_silu_bwd_f32(const float* x, const float* dy, float* dx, long long n, void* stream) {
+    if (!x || !dy || !dx) return mi355_fail(MI355_ERR_ARG, "silu_bwd: null pointer");
+    hipLaunchKernelGGL(silu_bwd_f32_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, ST, x, dy, dx, (size_t)n);
+    return mi355_check_launch("silu_bwd_f32");
+}
+int mi355_timestep_embed(const float* t, void* out, int B, int dim, void* stream) {
+    if (!t || !out || (dim & 1)) return mi355_fail(MI355_ERR_ARG, "timestep_embed: bad arguments");
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3((B * (dim / 2) + 255) / 256), dim3(256), 0, ST, t, (bf16_t*)out, B, dim);
+    return mi355_check_launch("timestep_embed");
+}
+int mi355_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream) {
+    if (!x || !y || (n & 7)) return mi355_fail(MI355_ERR_ARG, "cast_f32_to_bf16: n must be a multiple of 8");
+    ProfScope prof(FAM_ELEM, ST, (double)n * 6);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(GRID_FOR(n / 8, 256)), dim3(256), 0, ST, x, (bf16_t*)y, (size_t)n / 8);
+    return mi355_check_launch("cast_f32_to_bf16");
+}
+int mi355_cast_bf16_to_f32(const void* x, float* y, long long n, void* stream) {
+    if (!x || !y) return mi355_fail(MI355_ERR_ARG, "cast_bf16_to_f32: null pointer");
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, ST, (const bf16_t*)x, y, (size_t)n);
+    return mi355_check_launch("cast_bf16_to_f32");
+}
+int mi355_transpose_bf16(const void* in, void* out, int G, int R, int C, void* stream) {
+    if (!in || !out) return mi355_fail(MI355_ERR_ARG, "transpose: null pointer");
+    ProfScope prof(FAM_ELEM, ST, (double)G * R * C * 4);
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 31) / 32, (R + 31) / 32, G), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, R, C);
+    return mi355_check_launch("transpose_bf16");
+}
+int mi355_conv_weight_transpose(const void* w, void* wt, int Co, int taps, int Ci, void* stream) {
+    if (!w || !wt) return mi355_fail(MI355_ERR_ARG, "conv_weight_transpose: null pointer");
+    ProfScope prof(FAM_ELEM, ST, (double)Co * taps * Ci * 4);
+    hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32, taps), dim3(256), 0, ST, (const bf16_t*)w, (bf16_t*)wt, Co, taps, Ci);
+    return mi355_check_launch("conv_weight_transpose");
+}
+int mi355_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int Cs, int Cd, int HW, void* stream) {
+    if (!x || !y || Cd < Cs) return mi355_fail(MI355_ERR_ARG, "nchw_to_nhwc: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(GRID_FOR((size_t)B * HW * Cd, 256)), dim3(256), 0, ST, x, (bf16_t*)y, B, Cs, Cd, HW);
+    return mi355_check_launch("nchw_to_nhwc");
+}
+int mi355_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int Cs, int Cd, int HW, void* stream) {
+    if (!x || !y || Cd > Cs) return mi355_fail(MI355_ERR_ARG, "nhwc_to_nchw: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(GRID_FOR((size_t)B * HW * Cd, 256)), dim3(256), 0, ST, x, y, B, Cs, Cd, HW);
+    return mi355_check_launch("nhwc_to_nchw");
+}
+int mi355_sumpool2x2_bf16(const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+    if (!dy || !dx || (C & 7)) return mi355_fail(MI355_ERR_ARG, "sumpool2x2: bad arguments");
+    ProfScope prof(FAM_ELEM, ST, (double)B * H * W * C * 2 * 5);
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3(GRID_FOR((size_t)B * H * W * (C / 8), 256)), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
+    return mi355_check_launch("sumpool2x2");
+}
+// loss must point at one float; it is zeroed here.
+int mi355_mse_loss_fused(const float* pred, const float* target, float* grad, float* loss, long long n, void* stream) {
+    if (!pred || !target || !loss || n <= 0) return mi355_fail(MI355_ERR_ARG, "mse_loss: bad arguments");
+    if (hipMemsetAsync(loss, 0, sizeof(float), ST) != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "mse_loss: memset failed");
+    ProfScope prof(FAM_ELEM, ST, (double)n * 12);
+    hipLaunchKernelGGL(mse_fused_kernel, dim3(GRID_FOR(n, 1024)), dim3(256), 0, ST, pred, target, grad, loss, (size_t)n);
+    return mi355_check_launch("mse_loss_fused");
+}
+int mi355_ddpm_add_noise(const float* x0, const float* noise, const long long* t, const float* alphas_cumprod,
+                         float* out, int B, long long per_sample, void* stream) {
+    if (!x0 || !noise || !t || !alphas_cumprod || !out) return mi355_fail(MI355_ERR_ARG, "ddpm_add_noise: null pointer");
+    hipLaunchKernelGGL(ddpm_add_noise_kernel, dim3(GRID_FOR((size_t)B * per_sample, 256)), dim3(256), 0, ST, x0, noise, t, alphas_cumprod, out, B, (size_t)per_sample);
+    return mi355_check_launch("ddpm_add_noise");
+}
+int mi355_ddim_step_cfg(const float* eps, const float* x, float* out, const float* coef, long long n, int cfg, void* stream) {
+    if (!eps || !x || !out || !coef) return mi355_fail(MI355_ERR_ARG, "ddim_step: null pointer");
+    hipLaunchKernelGGL(ddim_step_cfg_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, ST, eps, x, out, coef, (size_t)n, cfg);
+    return mi355_check_launch("ddim_step_cfg");
+}
+// out (one float) is NOT zeroed here so several buffers can be accumulated; zero it first with mi355_zero_f32.
+int mi355_sumsq_f32(const float* g, float* out, long long n, void* stream) {
+    if (!g || !out) return mi355_fail(MI355_ERR_ARG, "sumsq: null pointer");
+    if (((uintptr_t)g) & 15) return mi355_fail(MI355_ERR_ARG, "sumsq: buffer must be 16-byte aligned");
+    ProfScope prof(FAM_ELEM, ST, (double)n * 4);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(GRID_FOR(n / 4 + 1, 1024)), dim3(256), 0, ST, g, out, (size_t)n);
+    return mi355_check_launch("sumsq");
+}
+int mi355_zero_f32(float* p, long long n, void* stream) {
+    if (!p) return mi355_fail(MI355_ERR_ARG, "zero: null pointer");
+    if (hipMemsetAsync(p, 0, (size_t)n * sizeof(float), ST) != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "zero: memset failed");
+    return MI355_OK;
+}
+int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
+                     long long n, void* stream) {
+    if (!p || !g || !m || !v || !hyper || !state) return mi355_fail(MI355_ERR_ARG, "adamw: null pointer");
+    if (n & 3) return mi355_fail(MI355_ERR_ARG, "adamw: n must be a multiple of 4 (pad the flat buffer)");
+    ProfScope prof(FAM_ELEM, ST, (double)n * 30);
+    hipLaunchKernelGGL(adamw_kernel, dim3(GRID_FOR(n / 4, 256)), dim3(256), 0, ST, p, g, m, v, (bf16_t*)p_bf16, hyper, state, (size_t)n);
+    return mi355_check_launch("adamw");
+}
+
+// scratch floats: 2*B*D (normalised copies) + 2*B (norms) + B*B (logits/dlogits) + 2*B (lse)
+long long mi355_contrastive_scratch_floats(int B, int D) { return 2LL * B * D + 2LL * B + 1LL * B * B + 2LL * B; }
+int mi355_contrastive_loss_fused(const float* text, const float* image, const float* log_temp, float* loss,
+                                 float* d_text, float* d_image, float* d_log_temp, float* scratch, int B, int D,
+                                 void* stream) {
+    if (!text || !image || !log_temp || !loss || !d_text || !d_image || !d_log_temp || !scratch)
+        return mi355_fail(MI355_ERR_ARG, "contrastive: null pointer");
+    if (B <= 0 || D <= 0 || D > 12288) return mi355_fail(MI355_ERR_ARG, "contrastive: bad shape");
+    float* th = scratch; float* ih = th + (size_t)B * D; float* tn = ih + (size_t)B * D; float* in_ = tn + B;
+    float* logits = in_ + B; float* lse = logits + (size_t)B * B;
+    hipMemsetAsync(loss, 0, sizeof(float), ST);
+    hipMemsetAsync(d_log_temp, 0, sizeof(float), ST);
+    ProfScope prof(FAM_ELEM, ST, 6.0 * B * B * D);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, ST, text, th, tn, B, D);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, ST, image, ih, in_, B, D);
+    int gx = (B + 3) / 4; if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(clip_logits_kernel, dim3(gx, B), dim3(256), 0, ST, th, ih, log_temp, logits, B, D);
+    hipLaunchKernelGGL(clip_lse_kernel, dim3(B, 2), dim3(256), 0, ST, logits, lse, B);
+    hipLaunchKernelGGL(clip_dlogits_kernel, dim3(B), dim3(256), 0, ST, logits, lse, loss, d_log_temp, B);
+    hipLaunchKernelGGL(clip_temp_clamp_kernel, dim3(1), dim3(1), 0, ST, log_temp, d_log_temp);
+    hipLaunchKernelGGL(clip_dembed_kernel, dim3(B), dim3(256), D * sizeof(float), ST, logits, ih, th, tn, log_temp, d_text, B, D, 0);
+    hipLaunchKernelGGL(clip_dembed_kernel, dim3(B), dim3(256), D * sizeof(float), ST, logits, th, ih, in_, log_temp, d_image, B, D, 1);
+    return mi355_check_launch("contrastive_loss_fused");
+}
+
+int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* stream) {
+    if (!x || !A || !t || (K & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_down: bad arguments (K%%8, 1<=R<=16)");
+    hipLaunchKernelGGL(lora_down_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)x, A, t, M, K, R);
+    return mi355_check_launch("lora_down");
+}
+int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* stream) {
+    if (!dy || !Bm || !dt || (N & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_dt: bad arguments");
+    hipLaunchKernelGGL(lora_dt_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha);
+    return mi355_check_launch("lora_dt");
+}
+int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int out_transposed,
+                     void* stream) {
+    if (!y || !t || !out || (C & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_outer: bad arguments");
+    if (hipMemsetAsync(out, 0, (size_t)C * R * sizeof(float), ST) != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "lora_outer: memset failed");
+    const int rows = 128;
+    hipLaunchKernelGGL(lora_outer_kernel, dim3((M + rows - 1) / rows), dim3(128), 0, ST, (const bf16_t*)y, t, out, M, C, R, scale, rows, out_transposed);
+    return mi355_check_launch("lora_outer");
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+// bf16 MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+//   out[M,N] = epilogue( sum_k A(m,k) * Bw[n,k] )
+//
+// A is either a dense row-major matrix (linear layers, 1x1 convolutions) or the *virtual* im2col
+// matrix of an NHWC activation (3x3 convolutions, stride 1/2, optional nearest-2x upsampled or
+// zero-dilated input), gathered on the fly by the tile loader - the im2col matrix never exists in
+// HBM.  Bw is always row-major [N][K] (K contiguous), which is how linear weights are stored and
+// how conv weights are stored as [Cout][ky][kx][Cin].
+//
+// Tile: 128 x BN x 64 per 256-thread workgroup (4 waves as 2x2, v_mfma_f32_16x16x32_bf16),
+// register-staged double-buffered LDS with an XOR swizzle so ds_read_b128 fragment reads are
+// conflict-free.  BN=160 divides every channel count of the SD-v1 denoiser (320/640/960/1280/...).
+// The epilogue stages fp32 accumulators through LDS so that bias / broadcast row bias (timestep
+// embedding) / LoRA rank-r update / residual are applied with 16-byte coalesced accesses.
+#include "common.h"
+
+struct ConvGeom {
+    int B, H, W, C;   // stored NHWC input
+    int Ho, Wo;       // output spatial size (M = B*Ho*Wo)
+    int stride;       // 1 or 2
+    int ups;          // 1: input is read through a nearest 2x upsample
+    int dil;          // 1: input is read through a zero-dilation by 2 (data-gradient of a stride-2 conv)
+    int ksize;        // 1 or 3
+};
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* Bw;
+    int M, N, K;
+    int lda, ldb;
+    void* out;
+    int ldo;
+    int out_fp32;
+    const float* bias;       // [N] or null
+    const float* rowbias;    // [M / rowbias_div][ld_rowbias] or null
+    int rowbias_div, ld_rowbias;
+    const bf16_t* residual;  // [M][ldr] or null
+    int ldr;
+    float alpha;
+    const float* lora_t;     // [M][lora_r] fp32 or null  (x A^T)
+    const float* lora_b;     // [N][lora_r] fp32          (B)
+    int lora_r;
+    float lora_alpha;
+    float* partial;          // split-K slabs [splitk][M][N] fp32
+    int splitk, kt_per_split;
+    int tiles_m, tiles_n;
+    ConvGeom g;
+};
+
+enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2 };
+
+template <int BN, int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int EP_LD = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+    // ---- block -> (tile_m, tile_n, split) with XCD-contiguous chunks of the logical grid
+    const int nwg = gridDim.x;
+    int lid = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = lid % p.tiles_n; lid /= p.tiles_n;
+    const int tile_m = lid % p.tiles_m;
+    const int split = lid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nkt_total = (p.K + BK - 1) / BK;
+    const int kt_begin = split * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split;
+    if (kt_end > nkt_total) kt_end = nkt_total;
+
+    // ---- per-thread loader state
+    const int cc = tid & 7;          // 16-byte chunk inside the 64-wide k slice
+    const int r0 = tid >> 3;         // first tile row handled (then +32 per step)
+    const bf16_t* a_base[A_CH];      // dense: row pointer; conv: pointer to pixel (b,0,0,0)
+    int a_iy0[A_CH], a_ix0[A_CH];
+    bool a_ok[A_CH];
+    const int pad = p.g.ksize >> 1;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        if constexpr (AMODE == AMODE_DENSE) {
+            a_base[i] = p.A + (size_t)mm * p.lda;
+            a_iy0[i] = a_ix0[i] = 0;
+        } else {
+            const int ox = mm % p.g.Wo;
+            const int t = mm / p.g.Wo;
+            const int oy = t % p.g.Ho;
+            const int b = t / p.g.Ho;
+            a_base[i] = p.A + (size_t)b * p.g.H * p.g.W * p.g.C;
+            a_iy0[i] = oy * p.g.stride - pad;
+            a_ix0[i] = ox * p.g.stride - pad;
+        }
+    }
+    const bf16_t* b_base[B_CH];
+    bool b_ok[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_ok[i] = n < p.N;
+        b_base[i] = p.Bw + (size_t)(b_ok[i] ? n : 0) * p.ldb;
+    }
+
+    bf16x8 a_reg[A_CH], b_reg[B_CH];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + cc * 8;
+        const bool k_ok = k < p.K;
+        if constexpr (AMODE == AMODE_DENSE) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i)
+                a_reg[i] = (a_ok[i] && k_ok) ? *(const bf16x8*)(a_base[i] + k) : zero8;
+        } else {
+            int tap, c;
+            if constexpr (AMODE == AMODE_CONV_FAST) {
+                const int kk = kt * BK;
+                tap = kk / p.g.C;              // wave-uniform
+                c = kk - tap * p.g.C + cc * 8;
+            } else {
+                tap = k / p.g.C;
+                c = k - tap * p.g.C;
+            }
+            int ky = 0, kx = 0;
+            if (p.g.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                int sy = a_iy0[i] + ky, sx = a_ix0[i] + kx;
+                bool ok = a_ok[i] && k_ok && sy >= 0 && sx >= 0;
+                if (p.g.dil) {
+                    ok = ok && !((sy | sx) & 1);
+                    sy >>= 1; sx >>= 1;
+                } else if (p.g.ups) {
+                    sy >>= 1; sx >>= 1;
+                }
+                ok = ok && sy < p.g.H && sx < p.g.W;
+                a_reg[i] = ok ? *(const bf16x8*)(a_base[i] + ((size_t)(sy * p.g.W + sx) * p.g.C + c)) : zero8;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            b_reg[i] = (b_ok[i] && k_ok) ? *(const bf16x8*)(b_base[i] + k) : zero8;
+    };
+    auto store_tile = [&](int stage) {
+        char* As = smem + stage * STAGE;
+        char* Bs = As + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int r = r0 + 32 * i;
+            *(bf16x8*)(As + r * 128 + ((cc ^ (r & 7)) << 4)) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int r = r0 + 32 * i;
+            *(bf16x8*)(Bs + r * 128 + ((cc ^ (r & 7)) << 4)) = b_reg[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1);
+        const char* As = smem + cur * STAGE;
+        const char* Bs = As + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+            const int ch = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm0 + i * 16 + fr;
+                af[i] = *(const bf16x8*)(As + r * 128 + ((ch ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn0 + j * 16 + fr;
+                bfr[j] = *(const bf16x8*)(Bs + r * 128 + ((ch ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- split-K: raw fp32 partial slab, the reduce kernel applies the epilogue
+    if (p.splitk > 1) {
+        float* dst = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm0 + i * 16 + fq * 4 + r;
+                    const int n = n0 + wn0 + j * 16 + fr;
+                    if (m < p.M && n < p.N) dst[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+
+    // ---- epilogue through LDS, 64 rows at a time
+    float* ep = (float*)smem;
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if ((wave >> 1) == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ep[(i * 16 + fq * 4 + r) * EP_LD + wn0 + j * 16 + fr] = acc[i][j][r];
+        }
+        __syncthreads();
+        constexpr int NC = BN / 8;
+        for (int idx = tid; idx < 64 * NC; idx += 256) {
+            const int row = idx / NC, c8 = idx - row * NC;
+            const int m = m0 + h * 64 + row, n = n0 + c8 * 8;
+            if (m >= p.M || n >= p.N) continue;
+            float v[8];
+            const f32x4 v0 = *(const f32x4*)(ep + row * EP_LD + c8 * 8);
+            const f32x4 v1 = *(const f32x4*)(ep + row * EP_LD + c8 * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] * p.alpha; v[4 + e] = v1[e] * p.alpha; }
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+            }
+            if (p.rowbias) {
+                const float* rb = p.rowbias + (size_t)(m / p.rowbias_div) * p.ld_rowbias + n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rb[e];
+            }
+            if (p.lora_t) {
+                const float* t = p.lora_t + (size_t)m * p.lora_r;
+                for (int r = 0; r < p.lora_r; ++r) {
+                    const float tv = t[r] * p.lora_alpha;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += tv * p.lora_b[(size_t)(n + e) * p.lora_r + r];
+                }
+            }
+            if (p.residual) {
+                const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            if (p.out_fp32) {
+                float* o = (float*)p.out + (size_t)m * p.ldo + n;
+                *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+                *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+                *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = ov;
+            }
+        }
+    }
+}
+
+// Sums the split-K slabs and applies the same epilogue as the fused path.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+    const int nc = p.N / 8;
+    const size_t total = (size_t)p.M * nc;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / nc), n = (int)(idx - (size_t)m * nc) * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < p.splitk; ++s) {
+            const float* src = p.partial + ((size_t)s * p.M + m) * p.N + n;
+            const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+        }
+        if (p.rowbias) {
+            const float* rb = p.rowbias + (size_t)(m / p.rowbias_div) * p.ld_rowbias + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rb[e];
+        }
+        if (p.lora_t) {
+            const float* t = p.lora_t + (size_t)m * p.lora_r;
+            for (int r = 0; r < p.lora_r; ++r) {
+                const float tv = t[r] * p.lora_alpha;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += tv * p.lora_b[(size_t)(n + e) * p.lora_r + r];
+            }
+        }
+        if (p.residual) {
+            const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        }
+        if (p.out_fp32) {
+            float* o = (float*)p.out + (size_t)m * p.ldo + n;
+            *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            bf16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+            *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = ov;
+        }
+    }
+}
+
+template <int BN, int AMODE>
+static int launch_gemm(const GemmArgs& a, hipStream_t s) {
+    constexpr int smem = 2 * (128 + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    const int grid = a.tiles_m * a.tiles_n * a.splitk;
+    hipLaunchKernelGGL((gemm_kernel<BN, AMODE>), dim3(grid), dim3(256), smem, s, a);
+    return mi355_check_launch("gemm_kernel");
+}
+
+static int pick_splitk(int tiles, int nkt) {
+    if (tiles >= 192) return 1;
+    int s = (384 + tiles - 1) / tiles;
+    if (s > nkt / 4) s = nkt / 4;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return mi355_fail(MI355_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    if ((a.N & 7) || (a.K & 7)) return mi355_fail(MI355_ERR_ARG, "gemm: N (%d) and K (%d) must be multiples of 8", a.N, a.K);
+    if ((a.ldb & 7) || (a.ldo & 7) || (amode == AMODE_DENSE && (a.lda & 7)))
+        return mi355_fail(MI355_ERR_ARG, "gemm: leading dimensions must be multiples of 8 elements");
+    if (a.residual && (a.ldr & 7)) return mi355_fail(MI355_ERR_ARG, "gemm: residual stride must be a multiple of 8");
+    if (a.rowbias && a.rowbias_div <= 0) return mi355_fail(MI355_ERR_ARG, "gemm: rowbias_div must be positive");
+    int bn;
+    if (a.N % 160 == 0) bn = 160;
+    else if (a.N <= 64) bn = 64;
+    else bn = 128;
+    a.tiles_m = (a.M + 127) / 128;
+    a.tiles_n = (a.N + bn - 1) / bn;
+    const int nkt = (a.K + 63) / 64;
+    int sk = pick_splitk(a.tiles_m * a.tiles_n, nkt);
+    while (sk > 1 && (size_t)sk * a.M * a.N * sizeof(float) > ws_bytes) --sk;
+    a.kt_per_split = (nkt + sk - 1) / sk;
+    sk = (nkt + a.kt_per_split - 1) / a.kt_per_split;
+    a.splitk = sk;
+    a.partial = (float*)ws;
+    ProfScope prof(FAM_GEMM, s, 2.0 * a.M * a.N * a.K);
+    int rc;
+#define DISPATCH(BN)                                                                       \
+    (amode == AMODE_DENSE ? launch_gemm<BN, AMODE_DENSE>(a, s)                             \
+     : amode == AMODE_CONV_FAST ? launch_gemm<BN, AMODE_CONV_FAST>(a, s)                   \
+                                : launch_gemm<BN, AMODE_CONV_GENERIC>(a, s))
+    if (bn == 160) rc = DISPATCH(160);
+    else if (bn == 64) rc = DISPATCH(64);
+    else rc = DISPATCH(128);
+#undef DISPATCH
+    if (rc) return rc;
+    if (sk > 1) {
+        const size_t total = (size_t)a.M * (a.N / 8);
+        int grid = (int)((total + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, a);
+        rc = mi355_check_launch("splitk_reduce_kernel");
+    }
+    return rc;
+}
+
+extern "C" {
+
+size_t mi355_gemm_workspace_bytes(int M, int N) {
+    // room for up to 16 split-K slabs, capped at 256 MiB (the launcher lowers the split to fit)
+    size_t b = (size_t)16 * M * N * sizeof(float);
+    const size_t cap = (size_t)256 << 20;
+    return b > cap ? cap : b;
+}
+
+int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
+                    int out_fp32, const float* bias, const float* rowbias, int rowbias_div, int ld_rowbias,
+                    const void* residual, int ldr, float alpha, const float* lora_t, const float* lora_b, int lora_r,
+                    float lora_alpha, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !Bw || !out) return mi355_fail(MI355_ERR_ARG, "gemm: null pointer");
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.out = out; a.ldo = ldo; a.out_fp32 = out_fp32; a.bias = bias; a.rowbias = rowbias; a.rowbias_div = rowbias_div;
+    a.ld_rowbias = ld_rowbias; a.residual = (const bf16_t*)residual; a.ldr = ldr; a.alpha = alpha;
+    a.lora_t = lora_t; a.lora_b = lora_b; a.lora_r = lora_r; a.lora_alpha = lora_alpha;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1};
+    return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, int ksize, int stride,
+                      int ups, int dil, int Ho, int Wo, void* out, int out_fp32, const float* bias,
+                      const float* rowbias, int ld_rowbias, const void* residual, float alpha, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!x || !w || !out) return mi355_fail(MI355_ERR_ARG, "conv2d: null pointer");
+    if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "conv2d: ksize %d (1 or 3 supported)", ksize);
+    if (stride != 1 && stride != 2) return mi355_fail(MI355_ERR_UNSUPPORTED, "conv2d: stride %d", stride);
+    if ((C & 7) || (Cout & 7)) return mi355_fail(MI355_ERR_ARG, "conv2d: channels must be multiples of 8 (C=%d Cout=%d)", C, Cout);
+    if (ups && dil) return mi355_fail(MI355_ERR_ARG, "conv2d: ups and dil are exclusive");
+    const int pad = ksize / 2;
+    const int Hv = ups ? 2 * H : (dil ? 2 * H : H), Wv = ups ? 2 * W : (dil ? 2 * W : W);
+    // dil: the virtual input is the zero-dilated map of size (2H-1 .. 2H); any Ho in that range is legal
+    if (!dil) {
+        if (Ho != (Hv + 2 * pad - ksize) / stride + 1 || Wo != (Wv + 2 * pad - ksize) / stride + 1)
+            return mi355_fail(MI355_ERR_ARG, "conv2d: output size %dx%d inconsistent with input %dx%d", Ho, Wo, Hv, Wv);
+    } else if (Ho > Hv || Wo > Wv || Ho < Hv - 1 || Wo < Wv - 1) {
+        return mi355_fail(MI355_ERR_ARG, "conv2d(dil): output size %dx%d inconsistent with input %dx%d", Ho, Wo, H, W);
+    }
+    GemmArgs a = {};
+    a.A = (const bf16_t*)x; a.Bw = (const bf16_t*)w;
+    a.M = B * Ho * Wo; a.N = Cout; a.K = ksize * ksize * C; a.lda = C; a.ldb = a.K;
+    a.out = out; a.ldo = Cout; a.out_fp32 = out_fp32; a.bias = bias; a.rowbias = rowbias; a.rowbias_div = Ho * Wo;
+    a.ld_rowbias = ld_rowbias; a.residual = (const bf16_t*)residual; a.ldr = Cout; a.alpha = alpha;
+    a.g = ConvGeom{B, H, W, C, Ho, Wo, stride, ups, dil, ksize};
+    const int amode = (C % 64 == 0) ? AMODE_CONV_FAST : AMODE_CONV_GENERIC;
+    return run_gemm(a, amode, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+// Weight-gradient GEMM for gfx950:  dW[co][tap][ci] (+)= sum_m dy[m][co] * xcol[m][tap][ci]
+//
+// The contraction runs over pixels/tokens m, which is the SLOW dimension of both operands
+// (dy is [M][Cout], x is NHWC).  Tiles are therefore staged in LDS in their natural
+// [pixel][channel] order with 16-byte coalesced copies and the MFMA fragments are fetched with the
+// gfx950 transposing LDS read (ds_read_b64_tr_b16), so no transposed copy of an activation is ever
+// written to HBM.  The im2col view of x (3x3 taps, stride 1/2, optional nearest-2x upsampled input)
+// is gathered by the loader; linear layers are the 1x1 / dense case.
+//
+// Tile: 160(co) x 160(ci) x 64 pixels per 256-thread workgroup (2x2 waves, 5x5 MFMA 16x16x32 each).
+// LDS row stride 352 B = 11 x 32 B keeps the 8 rows touched by one half-wave transposed read on
+// distinct banks.  The pixel range is split across workgroups (split-K); partial sums are combined
+// with fp32 atomics into a zero-initialised (or accumulating) fp32 gradient buffer.
+#include "common.h"
+
+struct WgradArgs {
+    const bf16_t* dy;   // [M][Cout]
+    const bf16_t* x;    // NHWC [B][H][W][Cin]  (or dense [M][Cin])
+    float* dw;          // [Cout][taps][Cin] fp32
+    int M, Cout, Cin;
+    int B, H, W, Ho, Wo, stride, ups, ksize;
+    int tiles_co, tiles_ci, taps, splits, kt_per_split;
+    int use_atomic;
+    int ldx;            // dense: row stride of x
+};
+
+constexpr int WG_BT = 160;          // channels per tile side
+constexpr int WG_BK = 64;           // pixels per k tile
+constexpr int WG_LD = 352;          // LDS row stride in bytes
+constexpr int WG_CH = 5;            // 16-byte chunks per thread per operand
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * WG_BK * WG_LD];
+    char* As = smem;                       // dy tile  [64][160]
+    char* Bs = smem + WG_BK * WG_LD;       // x tile   [64][160]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 80, wn0 = (wave & 1) * 80;
+
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid % p.splits; lid /= p.splits;
+    const int tile_ci = lid % p.tiles_ci; lid /= p.tiles_ci;
+    const int tile_co = lid % p.tiles_co;
+    const int tap = lid / p.tiles_co;
+    const int co0 = tile_co * WG_BT, ci0 = tile_ci * WG_BT;
+    int ky = 0, kx = 0;
+    if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
+    const int pad = p.ksize >> 1;
+
+    const int nkt_total = (p.M + WG_BK - 1) / WG_BK;
+    const int kt_begin = split * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split;
+    if (kt_end > nkt_total) kt_end = nkt_total;
+
+    // loader: thread -> one pixel row of the tile, chunks (tid&3) + 4*i
+    const int lp = tid >> 2, lc = tid & 3;
+    bf16x8 a_reg[WG_CH], b_reg[WG_CH];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto load_tile = [&](int kt) {
+        const int m = kt * WG_BK + lp;
+        const bool m_ok = m < p.M;
+        const bf16_t* arow = p.dy + (size_t)(m_ok ? m : 0) * p.Cout;
+        const bf16_t* brow;
+        bool b_ok = m_ok;
+        if (p.ksize == 1 && p.stride == 1 && !p.ups) {
+            brow = p.x + (size_t)(m_ok ? m : 0) * p.ldx;
+        } else {
+            const int mm = m_ok ? m : 0;
+            const int ox = mm % p.Wo;
+            const int t = mm / p.Wo;
+            const int oy = t % p.Ho;
+            const int b = t / p.Ho;
+            int sy = oy * p.stride - pad + ky, sx = ox * p.stride - pad + kx;
+            b_ok = b_ok && sy >= 0 && sx >= 0;
+            if (p.ups) { sy >>= 1; sx >>= 1; }
+            b_ok = b_ok && sy < p.H && sx < p.W;
+            brow = p.x + (b_ok ? ((size_t)(b * p.H + sy) * p.W + sx) * p.Cin : 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WG_CH; ++i) {
+            const int ch = (lc + 4 * i) * 8;
+            a_reg[i] = (m_ok && co0 + ch < p.Cout) ? *(const bf16x8*)(arow + co0 + ch) : zero8;
+            b_reg[i] = (b_ok && ci0 + ch < p.Cin) ? *(const bf16x8*)(brow + ci0 + ch) : zero8;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < WG_CH; ++i) {
+            const int off = lp * WG_LD + (lc + 4 * i) * 16;
+            *(bf16x8*)(As + off) = a_reg[i];
+            *(bf16x8*)(Bs + off) = b_reg[i];
+        }
+    };
+
+    f32x4 acc[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addressing: 16-lane group g reads pixels kbase + 4g + q (then +16), q = (lane&15)>>2,
+    // channels c0 + 4*(lane&3) .. +3; lane i of the group receives channel c0 + i for those 4 pixels.
+    const int g = lane >> 4, li = lane & 15;
+    const int tr_off = (4 * g + (li >> 2)) * WG_LD + (li & 3) * 8;
+
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();           // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[5], bfr[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const char* pa = As + ks * 32 * WG_LD + tr_off + (wm0 + i * 16) * 2;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa + 16 * WG_LD));
+                af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const char* pb = Bs + ks * 32 * WG_LD + tr_off + (wn0 + i * 16) * 2;
+                const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pb));
+                const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pb + 16 * WG_LD));
+                bfr[i] = bf16x8{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const int ktot = p.taps * p.Cin;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm0 + i * 16 + g * 4 + r;
+                const int ci = ci0 + wn0 + j * 16 + li;
+                if (co < p.Cout && ci < p.Cin) {
+                    float* dst = p.dw + (size_t)co * ktot + (size_t)tap * p.Cin + ci;
+                    if (p.use_atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
+                    else *dst = acc[i][j][r];
+                }
+            }
+}
+
+// Column sums of a bf16 matrix in segments of `seg` rows: out[s][n] = sum_{m in segment s} y[m][n].
+// Used for bias gradients (one segment) and the timestep-embedding broadcast gradient (one segment
+// per sample).  fp32 atomics combine the row-chunks of a segment; `out` must be zeroed by the caller.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ y, float* __restrict__ out, int M,
+                                                     int N, int seg, int rows_per_block) {
+    const int nc = N / 8;
+    const int chunks_per_seg = (seg + rows_per_block - 1) / rows_per_block;
+    const int s = blockIdx.x / chunks_per_seg, ck = blockIdx.x - s * chunks_per_seg;
+    const int r_begin = s * seg + ck * rows_per_block;
+    int r_end = r_begin + rows_per_block;
+    if (r_end > (s + 1) * seg) r_end = (s + 1) * seg;
+    if (r_end > M) r_end = M;
+    // thread -> column chunk (tid % nc8) with row phase (tid / nc8)
+    const int cpb = nc < 256 ? nc : 256;         // column chunks handled concurrently
+    const int rphase = 256 / cpb;
+    for (int c0 = 0; c0 < nc; c0 += cpb) {
+        const int c = c0 + (threadIdx.x % cpb);
+        const int rp = threadIdx.x / cpb;
+        if (c >= nc || rp >= rphase) continue;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = r_begin + rp; r < r_end; r += rphase) {
+            const bf16x8 t = *(const bf16x8*)(y + (size_t)r * N + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) unsafeAtomicAdd(out + (size_t)s * N + c * 8 + e, v[e]);
+    }
+}
+
+extern "C" {
+
+int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
+                     int stride, int ups, int Ho, int Wo, int accumulate, void* stream) {
+    if (!dy || !x || !dw) return mi355_fail(MI355_ERR_ARG, "wgrad: null pointer");
+    if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "wgrad: ksize %d", ksize);
+    if ((Cin & 7) || (Cout & 7)) return mi355_fail(MI355_ERR_ARG, "wgrad: channels must be multiples of 8");
+    WgradArgs a = {};
+    a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.dw = dw;
+    a.M = B * Ho * Wo; a.Cout = Cout; a.Cin = Cin; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+    a.stride = stride; a.ups = ups; a.ksize = ksize; a.ldx = Cin;
+    a.taps = ksize * ksize;
+    a.tiles_co = (Cout + WG_BT - 1) / WG_BT;
+    a.tiles_ci = (Cin + WG_BT - 1) / WG_BT;
+    const int tiles = a.tiles_co * a.tiles_ci * a.taps;
+    const int nkt = (a.M + WG_BK - 1) / WG_BK;
+    int s = (512 + tiles - 1) / tiles;
+    if (s > nkt / 4) s = nkt / 4;
+    if (s < 1) s = 1;
+    a.kt_per_split = (nkt + s - 1) / s;
+    a.splits = (nkt + a.kt_per_split - 1) / a.kt_per_split;
+    a.use_atomic = (a.splits > 1 || accumulate) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.splits > 1 && !accumulate) {
+        hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * a.taps * Cin * sizeof(float), st);
+        if (e != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed: %s", hipGetErrorString(e));
+    }
+    ProfScope prof(FAM_WGRAD, st, 2.0 * a.M * Cout * (double)a.taps * Cin);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a);
+    return mi355_check_launch("wgrad_kernel");
+}
+
+int mi355_colsum_bf16(const void* y, float* out, int M, int N, int seg, void* stream) {
+    if (!y || !out) return mi355_fail(MI355_ERR_ARG, "colsum: null pointer");
+    if ((N & 7) || seg <= 0 || M % seg) return mi355_fail(MI355_ERR_ARG, "colsum: N %% 8 == 0 and M %% seg == 0 required");
+    hipStream_t st = (hipStream_t)stream;
+    const int nseg = M / seg;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)nseg * N * sizeof(float), st);
+    if (e != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "colsum: memset failed: %s", hipGetErrorString(e));
+    int rows_per_block = 256;
+    if (rows_per_block > seg) rows_per_block = seg;
+    const int chunks = (seg + rows_per_block - 1) / rows_per_block;
+    ProfScope prof(FAM_ELEM, st, (double)M * N * 2);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nseg * chunks), dim3(256), 0, st, (const bf16_t*)y, out, M, N, seg,
+                       rows_per_block);
+    return mi355_check_launch("colsum_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+"""Low-rank adapters with the interface of /root/reference/lora.py:5-41.
+
+`LoRALinear(original_linear, r=4, alpha=1.0)` wraps either a torch `nn.Linear` living on the HIP
+device or one of this package's `HipLinear` layers.  y = W x + b + alpha * B (A x) is ONE MFMA
+GEMM: the rank-r product enters through the GEMM epilogue (`t = x A^T` is a skinny side product),
+the backward produces dx, dA, dB only (the frozen base weight gets no gradient).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from ._lib import lib, check
+from .ops import BF16, F32, _stream, gemm
+
+
+def _operands(original):
+    """(w16 [N][K], w16_t [K][N]) bf16 copies of the base weight, cached until the weight changes."""
+    pack = getattr(original, "pack", None)
+    if pack is not None and pack.w16 is not None:
+        return pack.w16, pack.w16_t
+    w = original.weight
+    key = (w.data_ptr(), w._version, w.device)
+    cache = getattr(original, "_mi355_lora_cache", None)
+    if cache is None or cache[0] != key:
+        w16 = w.detach().to(BF16).contiguous()
+        w16_t = torch.empty((w.shape[1], w.shape[0]), dtype=BF16, device=w.device)
+        check(lib.mi355_transpose_bf16(w16.data_ptr(), w16_t.data_ptr(), 1, w.shape[0], w.shape[1], _stream()), "transpose")
+        cache = (key, w16, w16_t)
+        original._mi355_lora_cache = cache
+    return cache[1], cache[2]
+
+
+class _LoraLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, b, bias, alpha, w16, w16_t):
+        if not x.is_cuda:
+            raise RuntimeError("LoRALinear: HIP device tensors required (no CPU path)")
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K).to(BF16).contiguous()
+        M, r, N = x2.shape[0], a.shape[0], b.shape[0]
+        af, bf = a.detach().to(F32).contiguous(), b.detach().to(F32).contiguous()
+        t = torch.empty((M, r), dtype=F32, device=x.device)
+        check(lib.mi355_lora_down(x2.data_ptr(), af.data_ptr(), t.data_ptr(), M, K, r, _stream()), "lora_down")
+        biasf = None if bias is None else bias.detach().to(F32).contiguous()
+        y = gemm(x2, w16, bias=biasf, lora_t=t, lora_b=bf, lora_alpha=alpha)
+        ctx.save_for_backward(x2, t, af, bf)
+        ctx.alpha, ctx.w16_t, ctx.xshape, ctx.xdtype = alpha, w16_t, x.shape, x.dtype
+        return y.view(*x.shape[:-1], N).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, t, af, bf = ctx.saved_tensors
+        M, K = x2.shape
+        N, r = bf.shape
+        dy2 = dy.reshape(-1, N).to(BF16).contiguous()
+        dt = torch.empty((M, r), dtype=F32, device=dy.device)
+        check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, ctx.alpha, _stream()), "lora_dt")
+        db = torch.empty((N, r), dtype=F32, device=dy.device)
+        check(lib.mi355_lora_outer(dy2.data_ptr(), t.data_ptr(), db.data_ptr(), M, N, r, ctx.alpha, 0, _stream()), "lora_outer")
+        da = torch.empty((r, K), dtype=F32, device=dy.device)
+        check(lib.mi355_lora_outer(x2.data_ptr(), dt.data_ptr(), da.data_ptr(), M, K, r, 1.0, 1, _stream()), "lora_outer")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx = dy W + dt A : the rank-r term rides in the epilogue of the data-gradient GEMM
+            dx = gemm(dy2, ctx.w16_t, lora_t=dt, lora_b=af.t().contiguous(), lora_alpha=1.0)
+            dx = dx.view(ctx.xshape).to(ctx.xdtype)
+        return dx, da, db, None, None, None, None
+
+
+class LoRALinear(nn.Module):
+    def __init__(self, original_linear, r=4, alpha=1.0):
+        super().__init__()
+        self.original = original_linear
+        self.r = r
+        self.alpha = alpha
+        dev = original_linear.weight.device
+        self.lora_A = nn.Linear(original_linear.in_features, r, bias=False, device=dev)
+        self.lora_B = nn.Linear(r, original_linear.out_features, bias=False, device=dev)
+        nn.init.kaiming_uniform_(self.lora_A.weight, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_B.weight)
+        for p in self.original.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        w16, w16_t = _operands(self.original)
+        return _LoraLinearFn.apply(x, self.lora_A.weight, self.lora_B.weight, self.original.bias, self.alpha, w16, w16_t)
+
+
+def extract_lora_weights(model):
+    out = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, LoRALinear):
+            out[f"{name}.lora_A"] = mod.lora_A.state_dict()
+            out[f"{name}.lora_B"] = mod.lora_B.state_dict()
+    return out
+
+
+def load_lora_weights(model, lora_weights):
+    for name, mod in model.named_modules():
+        if isinstance(mod, LoRALinear) and f"{name}.lora_A" in lora_weights:
+            mod.lora_A.load_state_dict(lora_weights[f"{name}.lora_A"])
+            mod.lora_B.load_state_dict(lora_weights[f"{name}.lora_B"])

@@ -1,0 +1,448 @@
+"""Tensor-level wrappers over the C ABI plus the torch.autograd.Function glue.
+
+PyTorch owns every buffer (allocation, streams, autograd bookkeeping); all arithmetic is done by
+libmi355_denoiser.so.  Activations are bf16, token-major / NHWC.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from ._lib import lib, check
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+_WORKSPACE = {}
+WORKSPACE_BYTES = 256 << 20
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def workspace(device):
+    ws = _WORKSPACE.get(device)
+    if ws is None:
+        ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _WORKSPACE[device] = ws
+    return ws
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: HIP device tensor required (no CPU path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: must be contiguous")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# raw calls
+# ------------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=False, alpha=1.0,
+         lora_t=None, lora_b=None, lora_alpha=0.0, out=None):
+    """out[M,N] = alpha * a[M,K] @ w[N,K]^T (+ bias + rowbias + lora + residual).  a may have a row stride."""
+    assert a.dtype == BF16 and w.dtype == BF16 and a.is_cuda
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if out_fp32 else BF16, device=a.device)
+    ws = workspace(a.device)
+    r = 0 if lora_t is None else lora_t.shape[1]
+    check(lib.mi355_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), K, M, N, K, out.data_ptr(), out.stride(0),
+                              1 if out.dtype == F32 else 0, _ptr(bias), _ptr(rowbias), rowbias_div,
+                              0 if rowbias is None else rowbias.stride(0), _ptr(residual),
+                              0 if residual is None else residual.stride(0), alpha, _ptr(lora_t), _ptr(lora_b), r,
+                              lora_alpha, ws.data_ptr(), ws.numel(), _stream()), "gemm")
+    return out
+
+
+def conv2d(x, w, cout, ksize, stride=1, ups=False, dil=False, out_hw=None, bias=None, rowbias=None, residual=None,
+           out_fp32=False):
+    """x [B,H,W,C] bf16 NHWC; w physical [Cout][k][k][C] bf16 -> [B,Ho,Wo,Cout]."""
+    B, H, W, C = x.shape
+    assert x.dtype == BF16 and x.is_contiguous()
+    pad = ksize // 2
+    if out_hw is None:
+        hv, wv = (2 * H, 2 * W) if ups else (H, W)
+        out_hw = ((hv + 2 * pad - ksize) // stride + 1, (wv + 2 * pad - ksize) // stride + 1)
+    Ho, Wo = out_hw
+    out = torch.empty((B, Ho, Wo, cout), dtype=F32 if out_fp32 else BF16, device=x.device)
+    ws = workspace(x.device)
+    check(lib.mi355_conv2d_bf16(x.data_ptr(), B, H, W, C, w.data_ptr(), cout, ksize, stride, int(ups), int(dil), Ho, Wo,
+                                out.data_ptr(), int(out_fp32), _ptr(bias), _ptr(rowbias),
+                                0 if rowbias is None else rowbias.stride(0), _ptr(residual), 1.0, ws.data_ptr(),
+                                ws.numel(), _stream()), "conv2d")
+    return out
+
+
+def wgrad(dy, x, cin, cout, ksize=1, stride=1, ups=False, geom=None, out=None, accumulate=False):
+    """fp32 [Cout][k*k][Cin].  Linear: dy [M,Cout], x [M,Cin].  Conv: geom=(B,H,W,Ho,Wo)."""
+    if geom is None:
+        B, H, W, Ho, Wo = dy.shape[0], 1, 1, 1, 1
+    else:
+        B, H, W, Ho, Wo = geom
+    if out is None:
+        out = torch.empty((cout, ksize * ksize, cin), dtype=F32, device=dy.device)
+    check(lib.mi355_wgrad_bf16(dy.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, cin, cout, ksize, stride, int(ups),
+                               Ho, Wo, int(accumulate), _stream()), "wgrad")
+    return out
+
+
+def colsum(y2d, seg=None):
+    M, N = y2d.shape
+    seg = M if seg is None else seg
+    out = torch.empty((M // seg, N), dtype=F32, device=y2d.device)
+    check(lib.mi355_colsum_bf16(y2d.data_ptr(), out.data_ptr(), M, N, seg, _stream()), "colsum")
+    return out
+
+
+def attention_fwd(q, k, v, heads):
+    """q [B,Nq,C], k/v [B,Nk,C] (last dim contiguous; row stride arbitrary multiple of 8)."""
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    D = C // heads
+    out = torch.empty((B, Nq, C), dtype=BF16, device=q.device)
+    lse = torch.empty((B, heads, Nq), dtype=F32, device=q.device)
+    check(lib.mi355_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, heads,
+                                  Nq, Nk, D, q.stride(1), k.stride(1), v.stride(1), C, 1.0 / math.sqrt(D), _stream()),
+          "attention_fwd")
+    return out, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, heads, dq, dk, dv):
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    D = C // heads
+    delta = torch.empty((B, heads, Nq), dtype=F32, device=q.device)
+    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    check(lib.mi355_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                  delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Nq, Nk, D,
+                                  q.stride(1), k.stride(1), v.stride(1), C, 1.0 / math.sqrt(D), _stream()),
+          "attention_bwd")
+
+
+def cast_bf16(x_f32, out=None):
+    n = x_f32.numel()
+    if out is None:
+        out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
+    check(lib.mi355_cast_f32_to_bf16(x_f32.data_ptr(), out.data_ptr(), n, _stream()), "cast")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd functions
+# ------------------------------------------------------------------------------------------------
+class WeightPack:
+    """bf16 operand copies of one (possibly fused) weight matrix, refreshed by the owning module.
+
+    w16   : [N][K] bf16 (forward operand)
+    w16_t : data-gradient operand: [K][N] for linear layers, [Cin][k][k][Cout] tap-flipped for convs.
+    """
+    __slots__ = ("w16", "w16_t", "n", "k", "ksize", "cin", "cout", "cin_pad", "cout_pad")
+
+    def __init__(self):
+        self.w16 = self.w16_t = None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) (+ residual); weights may be several row-stacked parameters (fused projections)."""
+
+    @staticmethod
+    def forward(ctx, x, pack, bias, residual, out_fp32, *weights):
+        x2 = x.reshape(-1, x.shape[-1])
+        res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
+        y = gemm(x2, pack.w16, bias=bias, residual=res2, out_fp32=out_fp32)
+        ctx.save_for_backward(x2)
+        ctx.pack = pack
+        ctx.xshape = x.shape
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.wshapes = [w.shape for w in weights]
+        ctx.wreq = [w.requires_grad for w in weights]
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        pack = ctx.pack
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        dy2 = dy2.contiguous()
+        dx = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dy2, pack.w16_t).view(ctx.xshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)[0]
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy2.view(dy.shape)
+        dws = [None] * len(ctx.wshapes)
+        if any(ctx.wreq):
+            dw = wgrad(dy2, x2, pack.k, pack.n).view(pack.n, pack.k)
+            r0 = 0
+            for i, shp in enumerate(ctx.wshapes):
+                if ctx.wreq[i]:
+                    dws[i] = dw[r0:r0 + shp[0]]
+                r0 += shp[0]
+        return (dx, None, db, dres, None, *dws)
+
+
+class ConvFn(torch.autograd.Function):
+    """NHWC convolution (3x3 / 1x1, stride 1/2, optional fused nearest-2x upsample of the input)
+    with bias, per-sample broadcast bias (timestep embedding) and residual fused in the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rowbias, residual, pack, stride, ups, out_fp32=False):
+        y = conv2d(x, pack.w16, pack.cout_pad, pack.ksize, stride=stride, ups=ups, bias=bias, rowbias=rowbias,
+                   residual=residual, out_fp32=out_fp32)
+        ctx.save_for_backward(x)
+        ctx.pack, ctx.stride, ctx.ups = pack, stride, ups
+        ctx.flags = (bias is not None, rowbias is not None, residual is not None)
+        ctx.wreq = weight.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        pack, stride, ups = ctx.pack, ctx.stride, ctx.ups
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        dy = dy.contiguous()
+        B, H, W, C = x.shape
+        _, Ho, Wo, Co = dy.shape
+        dx = dw = db = drb = dres = None
+        if ctx.needs_input_grad[0]:
+            hv, wv = (2 * H, 2 * W) if ups else (H, W)
+            dxv = conv2d(dy, pack.w16_t, pack.cin_pad, pack.ksize, stride=1, dil=(stride == 2), out_hw=(hv, wv))
+            if ups:
+                dx = torch.empty_like(x)
+                check(lib.mi355_sumpool2x2_bf16(dxv.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "sumpool2x2")
+            else:
+                dx = dxv
+        if ctx.wreq:
+            dwp = wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo))
+            dwp = dwp.view(pack.cout_pad, pack.ksize, pack.ksize, pack.cin_pad)
+            # logical OIHW view of the physical [O][kh][kw][I] buffer (channels_last), sliced to the true sizes
+            dw = dwp.permute(0, 3, 1, 2)[:pack.cout, :pack.cin]
+        dy2 = dy.view(-1, Co)
+        if ctx.flags[0] and ctx.needs_input_grad[2]:
+            db = colsum(dy2)[0][:pack.cout]
+        if ctx.flags[1] and ctx.needs_input_grad[3]:
+            drb = colsum(dy2, seg=Ho * Wo)
+        if ctx.flags[2] and ctx.needs_input_grad[4]:
+            dres = dy
+        return dx, dw, db, drb, dres, None, None, None, None
+
+
+class GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        B, H, W, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((B, groups, 2), dtype=F32, device=x.device)
+        scratch = torch.empty((B * C * 2,), dtype=F32, device=x.device)
+        check(lib.mi355_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                      scratch.data_ptr(), B, H * W, C, groups, eps, int(silu), _stream()), "groupnorm_fwd")
+        ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.groups, ctx.silu = groups, silu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma, beta = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, H, W, C = x.shape
+        G = ctx.groups
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(beta)
+        scratch = torch.empty((B * C * 2 + B * G * 2,), dtype=F32, device=x.device)
+        check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                      dx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), B, H * W, C, G,
+                                      int(ctx.silu), _stream()), "groupnorm_bwd")
+        return dx, dg, db, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        stats = torch.empty((M, 2), dtype=F32, device=x.device)
+        check(lib.mi355_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                      M, C, eps, _stream()), "layernorm_fwd")
+        ctx.save_for_backward(x, stats, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(gamma)
+        check(lib.mi355_layernorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                                      dg.data_ptr(), db.data_ptr(), M, C, _stream()), "layernorm_bwd")
+        return dx, dg, db, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v per head, no mask.
+
+    self-attention : qkv [B,N,3C] is the output of the fused q/k/v projection, kv is None;
+    cross-attention: q [B,N,C] and kv [B,T,2C] (fused k/v projection of the text embeddings).
+    The gradient comes back in the same fused layout, so no slicing/concatenation pass is needed.
+    """
+
+    @staticmethod
+    def forward(ctx, q_src, kv_src, heads):
+        if kv_src is None:
+            C = q_src.shape[2] // 3
+            q, k, v = q_src[:, :, :C], q_src[:, :, C:2 * C], q_src[:, :, 2 * C:]
+        else:
+            C = q_src.shape[2]
+            q, k, v = q_src, kv_src[:, :, :C], kv_src[:, :, C:]
+        o, lse = attention_fwd(q, k, v, heads)
+        ctx.save_for_backward(q_src, kv_src, o, lse)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q_src, kv_src, o, lse = ctx.saved_tensors
+        do = do.contiguous()
+        dq_src = torch.empty_like(q_src)
+        if kv_src is None:
+            C = q_src.shape[2] // 3
+            q, k, v = q_src[:, :, :C], q_src[:, :, C:2 * C], q_src[:, :, 2 * C:]
+            dq, dk, dv = dq_src[:, :, :C], dq_src[:, :, C:2 * C], dq_src[:, :, 2 * C:]
+            dkv_src = None
+        else:
+            C = q_src.shape[2]
+            dkv_src = torch.empty_like(kv_src)
+            q, k, v = q_src, kv_src[:, :, :C], kv_src[:, :, C:]
+            dq, dk, dv = dq_src, dkv_src[:, :, :C], dkv_src[:, :, C:]
+        attention_bwd(q, k, v, o, do, lse, ctx.heads, dq, dk, dv)
+        return dq_src, dkv_src, None
+
+
+class GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        F2 = x.shape[-1]
+        M = x.numel() // F2
+        y = torch.empty((*x.shape[:-1], F2 // 2), dtype=BF16, device=x.device)
+        check(lib.mi355_geglu_fwd(x.data_ptr(), y.data_ptr(), M, F2 // 2, _stream()), "geglu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        F2 = x.shape[-1]
+        M = x.numel() // F2
+        dx = torch.empty_like(x)
+        check(lib.mi355_geglu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), M, F2 // 2, _stream()), "geglu_bwd")
+        return dx
+
+
+class SiluF32ToBf16Fn(torch.autograd.Function):
+    """fp32 in -> bf16 out (timestep-embedding MLP activations)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty(x.shape, dtype=BF16, device=x.device)
+        check(lib.mi355_silu_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "silu")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dyf = dy.to(F32).contiguous()
+        dx = torch.empty_like(x)
+        check(lib.mi355_silu_bwd_f32(x.data_ptr(), dyf.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "silu_bwd")
+        return dx
+
+
+class MseLossFn(torch.autograd.Function):
+    """mean((pred - target)^2) with the gradient produced in the same pass
+    (reference objective: /root/reference/generator/image_generator.py:125)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = _req(pred, F32, "mse pred")
+        target = _req(target.to(F32), F32, "mse target")
+        loss = torch.empty((), dtype=F32, device=pred.device)
+        grad = torch.empty_like(pred) if pred.requires_grad else None
+        check(lib.mi355_mse_loss_fused(pred.data_ptr(), target.data_ptr(), _ptr(grad), loss.data_ptr(), pred.numel(),
+                                       _stream()), "mse_loss")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        return ctx.grad * dl, None
+
+
+def mse_loss(pred, target):
+    return MseLossFn.apply(pred, target)
+
+
+def timestep_embedding(t_float, dim):
+    B = t_float.shape[0]
+    out = torch.empty((B, dim), dtype=BF16, device=t_float.device)
+    check(lib.mi355_timestep_embed(t_float.data_ptr(), out.data_ptr(), B, dim, _stream()), "timestep_embed")
+    return out
+
+
+def nchw_to_nhwc_bf16(x, cpad):
+    B, C, H, W = x.shape
+    x = _req(x.to(F32), F32, "nchw input")
+    y = torch.empty((B, H, W, cpad), dtype=BF16, device=x.device)
+    check(lib.mi355_nchw_f32_to_nhwc_bf16(x.data_ptr(), y.data_ptr(), B, C, cpad, H * W, _stream()), "nchw_to_nhwc")
+    return y
+
+
+class ToNHWCFn(torch.autograd.Function):
+    """fp32 NCHW [B,C,H,W] -> bf16 NHWC [B,H,W,cpad] (zero-padded channels)."""
+
+    @staticmethod
+    def forward(ctx, x, cpad):
+        ctx.c = x.shape[1]
+        return nchw_to_nhwc_bf16(x, cpad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[..., :ctx.c].permute(0, 3, 1, 2).to(F32), None
+
+
+class ToNCHWFn(torch.autograd.Function):
+    """fp32 NHWC [B,H,W,Cs] -> fp32 NCHW [B,Cd,H,W] keeping the first Cd channels."""
+
+    @staticmethod
+    def forward(ctx, x, cd):
+        B, H, W, Cs = x.shape
+        y = torch.empty((B, cd, H, W), dtype=F32, device=x.device)
+        check(lib.mi355_nhwc_f32_to_nchw_f32(x.data_ptr(), y.data_ptr(), B, Cs, cd, H * W, _stream()), "nhwc_to_nchw")
+        ctx.cs = Cs
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = dy.permute(0, 2, 3, 1)
+        return torch.nn.functional.pad(g, (0, ctx.cs - g.shape[-1])).contiguous(), None

@@ -1,0 +1,142 @@
+/* C ABI of libmi355_denoiser.so - hand-written gfx950 (MI355X) kernels for the text-conditioned
+ * denoiser train/sampling step.
+ *
+ * The reference (hyomin777/image-generator) has no native layer and no FFI: every operation below
+ * replaces arithmetic that the reference reaches through third-party Python calls.  Each entry point
+ * names the reference call site whose arithmetic it carries:
+ *   - generator/image_generator.py:124  `self.unet(scaled_latent, t, encoder_hidden_states=...)` (train)
+ *   - generator/image_generator.py:93-95 the same network inside the sampling loop
+ *   - generator/image_generator.py:125  `F.mse_loss(noise_pred, noise)`
+ *   - generator/image_generator.py:116  `scheduler.add_noise`, :97-99 guidance + `infer_scheduler.step`
+ *   - lora.py:23-24                     `original(x) + alpha * lora_B(lora_A(x))`
+ *   - loss.py:16-28                     `ContrastiveLoss.forward`
+ *   - trainer.py:257-259                grad-norm clip + AdamW step (`scaler.step(optimizer)`)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch owns all buffers); the library
+ *     allocates no persistent device memory and frees nothing;
+ *   - activations are bf16, token-major / NHWC: a feature map is [B][H][W][C] == [B*H*W][C];
+ *   - `stream` is a hipStream_t; all work is enqueued asynchronously on it, no call synchronises;
+ *   - return value 0 = ok, negative = error (MI355_ERR_*); mi355_last_error() gives the message
+ *     (thread local).  No C++ exception crosses this boundary;
+ *   - "workspace"/"scratch" arguments are caller-provided device buffers of the documented size.
+ */
+#ifndef MI355_DENOISER_H
+#define MI355_DENOISER_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_ERR_ARG (-1)
+#define MI355_ERR_LAUNCH (-2)
+#define MI355_ERR_UNSUPPORTED (-3)
+
+const char* mi355_last_error(void);
+int mi355_abi_version(void);
+
+/* Launch timing (HIP events on the launch stream around every call of a kernel family).
+ * Families: 0 gemm/conv, 1 weight-gradient, 2 attention, 3 normalisation, 4 elementwise. */
+int mi355_prof_enable(int on);
+int mi355_prof_collect(double* ms, double* work, long long* count);
+
+/* ---- contractions (image_generator.py:124: Linear / Conv2d layers of the denoiser) -------------
+ * out[M][N] = alpha * A[M][K] . Bw[N][K]^T + bias[n] + rowbias[m / rowbias_div][n]
+ *             + lora_alpha * (lora_t[m][:] . lora_b[n][:]) + residual[m][n]
+ * A, Bw, residual bf16; bias, rowbias, lora_t ([M][r]), lora_b ([N][r]) fp32; out bf16 or fp32.
+ * Optional pointers may be NULL.  N, K and all leading dimensions must be multiples of 8. */
+size_t mi355_gemm_workspace_bytes(int M, int N);
+int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
+                    int out_fp32, const float* bias, const float* rowbias, int rowbias_div, int ld_rowbias,
+                    const void* residual, int ldr, float alpha, const float* lora_t, const float* lora_b, int lora_r,
+                    float lora_alpha, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Implicit-GEMM convolution, NHWC bf16.  x [B][H][W][C]; w [Cout][k][k][C]; out [B][Ho][Wo][Cout].
+ * ksize 1|3 (padding k/2), stride 1|2; ups=1 reads x through a nearest 2x upsample; dil=1 reads x
+ * through a zero-dilation by 2 (data gradient of a stride-2 convolution, with w = flipped/transposed
+ * weights).  rowbias is [B][ld_rowbias] (broadcast over pixels: timestep-embedding projection). */
+int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, int ksize, int stride,
+                      int ups, int dil, int Ho, int Wo, void* out, int out_fp32, const float* bias,
+                      const float* rowbias, int ld_rowbias, const void* residual, float alpha, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* Weight gradient dw[Cout][k*k][Cin] (fp32) = sum over output pixels of dy[m][co] * im2col(x)[m][tap][ci].
+ * Linear layers: ksize=1, H=W=Ho=Wo=1, B = rows.  accumulate=0 overwrites dw, 1 adds to it. */
+int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
+                     int stride, int ups, int Ho, int Wo, int accumulate, void* stream);
+
+/* out[s][n] = sum of the rows of segment s (seg rows each) of y[M][N] (bias / broadcast gradients). */
+int mi355_colsum_bf16(const void* y, float* out, int M, int N, int seg, void* stream);
+
+/* ---- attention (self- and cross-attention of the transformer blocks) ---------------------------
+ * q [B][Nq][H*D] (row stride ldq), k/v [B][Nk][H*D] (ldk, ldv), out [B][Nq][H*D] (ldo); no mask
+ * (image_generator.py:124 passes none).  lse [B][H][Nq] receives log2-domain row statistics. */
+int mi355_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Nq,
+                        int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+int mi355_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                        float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int D, int ldq,
+                        int ldk, int ldv, int ldo, float scale, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------------
+ * GroupNorm over [B][HW][C] with G groups, optional fused SiLU.  stats [B][G][2] = (mean, rstd).
+ * fwd scratch: B*C*2 floats; bwd scratch: B*C*2 + B*G*2 floats. */
+int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* scratch,
+                        int B, int HW, int C, int G, float eps, int silu, void* stream);
+int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                        void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
+                        void* stream);
+/* LayerNorm over rows of [M][C]; stats [M][2] = (mean, rstd). */
+int mi355_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C,
+                        float eps, void* stream);
+int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx,
+                        float* dgamma, float* dbeta, int M, int C, void* stream);
+
+/* ---- elementwise / layout -----------------------------------------------------------------------*/
+int mi355_geglu_fwd(const void* in, void* out, long long M, int F, void* stream);           /* in [M][2F] */
+int mi355_geglu_bwd(const void* in, const void* dout, void* din, long long M, int F, void* stream);
+int mi355_silu_f32_to_bf16(const float* x, void* y, long long n, void* stream);
+int mi355_silu_bwd_f32(const float* x, const float* dy, float* dx, long long n, void* stream);
+int mi355_timestep_embed(const float* t, void* out, int B, int dim, void* stream);          /* cos | sin */
+int mi355_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
+int mi355_cast_bf16_to_f32(const void* x, float* y, long long n, void* stream);
+int mi355_transpose_bf16(const void* in, void* out, int G, int R, int C, void* stream);    /* [G][R][C]->[G][C][R] */
+int mi355_conv_weight_transpose(const void* w, void* wt, int Co, int taps, int Ci, void* stream);
+int mi355_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int Cs, int Cd, int HW, void* stream);
+int mi355_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int Cs, int Cd, int HW, void* stream);
+int mi355_sumpool2x2_bf16(const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+
+/* ---- objectives (image_generator.py:125 and loss.py:16-28) ---------------------------------------
+ * loss = mean((pred - target)^2); grad (optional) = 2 (pred - target) / n.  loss is one device float. */
+int mi355_mse_loss_fused(const float* pred, const float* target, float* grad, float* loss, long long n, void* stream);
+long long mi355_contrastive_scratch_floats(int B, int D);
+int mi355_contrastive_loss_fused(const float* text, const float* image, const float* log_temp, float* loss,
+                                 float* d_text, float* d_image, float* d_log_temp, float* scratch, int B, int D,
+                                 void* stream);
+
+/* ---- diffusion schedule (image_generator.py:116 and :97-99) --------------------------------------*/
+int mi355_ddpm_add_noise(const float* x0, const float* noise, const long long* t, const float* alphas_cumprod,
+                         float* out, int B, long long per_sample, void* stream);
+/* coef (device) = {alpha_bar_t, alpha_bar_prev, guidance}; eps = [uncond | text] when cfg != 0. */
+int mi355_ddim_step_cfg(const float* eps, const float* x, float* out, const float* coef, long long n, int cfg,
+                        void* stream);
+
+/* ---- optimizer (trainer.py:257-259) ---------------------------------------------------------------
+ * hyper (device floats): lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_grad_norm,
+ * grad pre-scale.  state (device floats): [0] = sum of squared gradients.  Non-finite norm skips. */
+int mi355_sumsq_f32(const float* g, float* out, long long n, void* stream);
+int mi355_zero_f32(float* p, long long n, void* stream);
+int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
+                     long long n, void* stream);
+
+/* ---- LoRA (lora.py:23-24): rank-r side products around the fused GEMM epilogue --------------------*/
+int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* stream);       /* t = x A^T */
+int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* stream);
+int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int out_transposed,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,400 @@
+"""Per-kernel parity: each HIP kernel (called through the C ABI) against plain fp32 torch math on
+the same seeded inputs.  Inputs are rounded to bf16 first so both sides see identical operands;
+tolerances are stated per test (bf16 outputs carry 2^-8 relative rounding)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g}, ref max {float(ref.abs().max()):.4g}"
+
+
+def rel_l2(got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    return float((got - ref).norm() / (ref.norm() + 1e-12))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (300, 640, 768), (128, 64, 128), (1000, 128, 72), (64, 1280, 5120),
+                                   (512, 1280, 11520), (77, 2560, 1280)])
+def test_gemm_plain(M, N, K):
+    from image_generator_amd import ops
+    a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
+    out = ops.gemm(a.to(dev()), w.to(dev()))
+    ref = a.float() @ w.float().t()
+    close(out, ref, 2 ** -7, 2e-2, f"gemm {M}x{N}x{K}")
+    assert rel_l2(out, ref) < 4e-3
+
+
+def test_gemm_epilogues():
+    from image_generator_amd import ops
+    M, N, K, r = 512, 320, 640, 4
+    a, w = rnd(M, K, seed=3), rnd(N, K, scale=K ** -0.5, seed=4)
+    bias = torch.randn(N)
+    rowbias = torch.randn(M // 128, N)
+    res = rnd(M, N, seed=5)
+    lt = torch.randn(M, r)
+    lb = torch.randn(N, r) * 0.1
+    d = dev()
+    out = ops.gemm(a.to(d), w.to(d), bias=bias.to(d), rowbias=rowbias.to(d), rowbias_div=128, residual=res.to(d),
+                   lora_t=lt.to(d), lora_b=lb.to(d), lora_alpha=0.5)
+    ref = a.float() @ w.float().t() + bias + rowbias.repeat_interleave(128, 0) + res.float() + 0.5 * lt @ lb.t()
+    close(out, ref, 2 ** -7, 2e-2, "gemm epilogue")
+    out32 = ops.gemm(a.to(d), w.to(d), bias=bias.to(d), out_fp32=True)
+    close(out32, a.float() @ w.float().t() + bias, 1e-4, 1e-3, "gemm fp32 out")
+
+
+def _conv_ref(x_nhwc, w_okki, bias, stride, ups):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    w = w_okki.float().permute(0, 3, 1, 2)
+    k = w.shape[-1]
+    return F.conv2d(x, w, bias, stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,H,W,C,Co,k,stride,ups", [
+    (2, 16, 16, 64, 128, 3, 1, False), (2, 16, 16, 320, 320, 3, 1, False), (2, 16, 16, 128, 128, 3, 2, False),
+    (2, 8, 8, 64, 64, 3, 1, True), (3, 8, 8, 8, 320, 3, 1, False), (2, 8, 8, 320, 8, 3, 1, False),
+    (2, 16, 16, 640, 320, 1, 1, False), (1, 4, 4, 2560, 1280, 3, 1, False), (2, 7, 9, 72, 64, 3, 2, False)])
+def test_conv2d(B, H, W, C, Co, k, stride, ups):
+    from image_generator_amd import ops
+    x = rnd(B, H, W, C, seed=6)
+    w = rnd(Co, k, k, C, scale=(k * k * C) ** -0.5, seed=7)
+    bias = torch.randn(Co) * 0.1
+    d = dev()
+    out = ops.conv2d(x.to(d), w.to(d), Co, k, stride=stride, ups=ups, bias=bias.to(d))
+    ref = _conv_ref(x, w, bias, stride, ups)
+    assert tuple(out.shape) == tuple(ref.shape)
+    close(out, ref, 2 ** -7, 2e-2, "conv2d")
+
+
+def test_conv2d_rowbias_residual():
+    from image_generator_amd import ops
+    B, H, W, C, Co = 3, 8, 8, 64, 160
+    x, w = rnd(B, H, W, C, seed=8), rnd(Co, 3, 3, C, scale=(9 * C) ** -0.5, seed=9)
+    rb = torch.randn(B, Co)
+    res = rnd(B, H, W, Co, seed=10)
+    d = dev()
+    out = ops.conv2d(x.to(d), w.to(d), Co, 3, rowbias=rb.to(d), residual=res.to(d))
+    ref = _conv_ref(x, w, None, 1, False) + rb[:, None, None, :] + res.float()
+    close(out, ref, 2 ** -7, 2e-2, "conv2d rowbias+residual")
+
+
+@pytest.mark.parametrize("B,H,W,C,Co,k,stride,ups", [
+    (2, 16, 16, 64, 128, 3, 1, False), (2, 16, 16, 128, 64, 3, 2, False), (2, 8, 8, 64, 64, 3, 1, True),
+    (4, 8, 8, 320, 320, 3, 1, False), (2, 8, 8, 128, 64, 1, 1, False), (2, 9, 7, 72, 64, 3, 2, False)])
+def test_conv_backward(B, H, W, C, Co, k, stride, ups):
+    """Data and weight gradients of the convolution against torch autograd."""
+    from image_generator_amd import ops
+    from image_generator_amd.ops import lib, check, _stream
+    x = rnd(B, H, W, C, seed=11)
+    w = rnd(Co, k, k, C, scale=(k * k * C) ** -0.5, seed=12)
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    ref = _conv_ref(xr, wr, None, stride, ups)
+    dy = rnd(*ref.shape, seed=13)
+    ref.backward(dy.float())
+    d = dev()
+    wt = torch.empty((C, k, k, Co), dtype=BF, device=d)
+    wd = w.to(d)
+    check(lib.mi355_conv_weight_transpose(wd.data_ptr(), wt.data_ptr(), Co, k * k, C, _stream()))
+    hv, wv = (2 * H, 2 * W) if ups else (H, W)
+    dxv = ops.conv2d(dy.to(d), wt, C, k, stride=1, dil=(stride == 2), out_hw=(hv, wv))
+    if ups:
+        dx = torch.empty((B, H, W, C), dtype=BF, device=d)
+        check(lib.mi355_sumpool2x2_bf16(dxv.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()))
+    else:
+        dx = dxv
+    assert rel_l2(dx, xr.grad) < 8e-3, rel_l2(dx, xr.grad)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    dw = ops.wgrad(dy.to(d), x.to(d), C, Co, k, stride, ups, geom=(B, H, W, Ho, Wo)).view(Co, k, k, C)
+    assert rel_l2(dw, wr.grad) < 2e-3, rel_l2(dw, wr.grad)
+    close(dw, wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), "wgrad conv")
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (777, 640, 768), (32, 1280, 1280), (8192, 2560, 320)])
+def test_linear_backward(M, N, K):
+    from image_generator_amd import ops
+    from image_generator_amd.ops import lib, check, _stream
+    x, w, dy = rnd(M, K, seed=14), rnd(N, K, scale=K ** -0.5, seed=15), rnd(M, N, seed=16)
+    d = dev()
+    wt = torch.empty((K, N), dtype=BF, device=d)
+    wd = w.to(d)
+    check(lib.mi355_transpose_bf16(wd.data_ptr(), wt.data_ptr(), 1, N, K, _stream()))
+    assert torch.equal(wt.cpu(), w.t().contiguous())
+    dx = ops.gemm(dy.to(d), wt)
+    assert rel_l2(dx, dy.float() @ w.float()) < 5e-3
+    dw = ops.wgrad(dy.to(d), x.to(d), K, N).view(N, K)
+    ref = dy.float().t() @ x.float()
+    assert rel_l2(dw, ref) < 1e-3, rel_l2(dw, ref)
+    db = ops.colsum(dy.to(d))[0]
+    close(db, dy.float().sum(0), 1e-3, 1e-2, "colsum")
+    if M % 32 == 0:
+        seg = ops.colsum(dy.to(d), seg=M // 32)
+        close(seg, dy.float().view(32, M // 32, N).sum(1), 1e-3, 1e-2, "colsum seg")
+
+
+@pytest.mark.parametrize("B,HW,C,G,silu", [(2, 256, 320, 32, True), (3, 64, 640, 32, False), (2, 16, 2560, 32, True),
+                                           (2, 64, 64, 8, True), (1, 1024, 960, 32, True), (2, 49, 1920, 32, False)])
+def test_groupnorm(B, HW, C, G, silu):
+    from image_generator_amd.ops import GroupNormFn
+    h = int(math.isqrt(HW))
+    x = (rnd(B, h, HW // h, C, seed=17).float() * 1.5 + 0.3).to(BF)
+    gamma, beta = torch.randn(C) * 0.2 + 1.0, torch.randn(C) * 0.1
+    dy = rnd(B, h, HW // h, C, seed=18)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.group_norm(xr.permute(0, 3, 1, 2), G, gr, br, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    ref.backward(dy.float())
+    d = dev()
+    xg = x.to(d).requires_grad_(True)
+    gg, bg = gamma.to(d).requires_grad_(True), beta.to(d).requires_grad_(True)
+    y = GroupNormFn.apply(xg, gg, bg, G, 1e-5, silu)
+    y.backward(dy.to(d))
+    close(y, ref, 2 ** -7, 2e-2, "gn fwd")
+    assert rel_l2(xg.grad, xr.grad) < 1e-2, rel_l2(xg.grad, xr.grad)
+    assert rel_l2(gg.grad, gr.grad) < 2e-3 and rel_l2(bg.grad, br.grad) < 2e-3
+
+
+@pytest.mark.parametrize("M,C", [(1000, 320), (64, 1280), (4096, 640), (7, 64)])
+def test_layernorm(M, C):
+    from image_generator_amd.ops import LayerNormFn
+    x = rnd(M, C, seed=19)
+    gamma, beta = torch.randn(C) * 0.2 + 1.0, torch.randn(C) * 0.1
+    dy = rnd(M, C, seed=20)
+    xr, gr, br = x.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    ref.backward(dy.float())
+    d = dev()
+    xg, gg, bg = x.to(d).requires_grad_(True), gamma.to(d).requires_grad_(True), beta.to(d).requires_grad_(True)
+    y = LayerNormFn.apply(xg, gg, bg, 1e-5)
+    y.backward(dy.to(d))
+    close(y, ref, 2 ** -7, 2e-2, "ln fwd")
+    assert rel_l2(xg.grad, xr.grad) < 1e-2
+    assert rel_l2(gg.grad, gr.grad) < 2e-3 and rel_l2(bg.grad, br.grad) < 2e-3
+
+
+def _attn_ref(q, k, v, heads):
+    B, Nq, C = q.shape
+    D = C // heads
+    qh = q.view(B, Nq, heads, D).transpose(1, 2)
+    kh = k.view(B, -1, heads, D).transpose(1, 2)
+    vh = v.view(B, -1, heads, D).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(D), -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("B,H,N,D", [(2, 8, 256, 40), (2, 8, 64, 80), (2, 8, 16, 160), (1, 4, 300, 16), (1, 4, 100, 32),
+                                     (1, 8, 1024, 40)])
+def test_self_attention(B, H, N, D):
+    from image_generator_amd.ops import AttentionFn
+    C = H * D
+    qkv = rnd(B, N, 3 * C, seed=21)
+    do = rnd(B, N, C, seed=22)
+    r = qkv.float().requires_grad_(True)
+    ref = _attn_ref(r[..., :C], r[..., C:2 * C], r[..., 2 * C:], H)
+    ref.backward(do.float())
+    g = qkv.to(dev()).requires_grad_(True)
+    o = AttentionFn.apply(g, None, H)
+    o.backward(do.to(dev()))
+    close(o, ref, 2 ** -6, 1e-2, "attn fwd")
+    assert rel_l2(o, ref) < 6e-3
+    assert rel_l2(g.grad, r.grad) < 1.5e-2, rel_l2(g.grad, r.grad)
+
+
+@pytest.mark.parametrize("B,H,N,T,D", [(2, 8, 256, 77, 40), (2, 8, 64, 77, 160), (2, 4, 64, 16, 16), (1, 8, 16, 13, 80)])
+def test_cross_attention(B, H, N, T, D):
+    from image_generator_amd.ops import AttentionFn
+    C = H * D
+    q, kv, do = rnd(B, N, C, seed=23), rnd(B, T, 2 * C, seed=24), rnd(B, N, C, seed=25)
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref = _attn_ref(qr, kvr[..., :C], kvr[..., C:], H)
+    ref.backward(do.float())
+    qg, kvg = q.to(dev()).requires_grad_(True), kv.to(dev()).requires_grad_(True)
+    o = AttentionFn.apply(qg, kvg, H)
+    o.backward(do.to(dev()))
+    close(o, ref, 2 ** -6, 1e-2, "xattn fwd")
+    assert rel_l2(qg.grad, qr.grad) < 1.5e-2, rel_l2(qg.grad, qr.grad)
+    assert rel_l2(kvg.grad, kvr.grad) < 1.5e-2, rel_l2(kvg.grad, kvr.grad)
+
+
+def test_attention_softmax_spike():
+    """One key dominates late in the sequence so the running max jumps between key tiles."""
+    from image_generator_amd.ops import AttentionFn
+    B, H, N, D = 1, 2, 256, 40
+    C = H * D
+    qkv = rnd(B, N, 3 * C, seed=26).float()
+    qkv[0, 200, C:2 * C] = qkv[0, 5, :C] * 6.0     # key 200 aligned with query 5
+    qkv = qkv.to(BF)
+    r = qkv.float()
+    ref = _attn_ref(r[..., :C], r[..., C:2 * C], r[..., 2 * C:], H)
+    o = AttentionFn.apply(qkv.to(dev()), None, H)
+    close(o, ref, 2 ** -6, 1e-2, "attn spike")
+
+
+def test_geglu_and_silu():
+    from image_generator_amd.ops import GegluFn, SiluF32ToBf16Fn
+    x, dy = rnd(300, 2 * 640, seed=27), rnd(300, 640, seed=28)
+    xr = x.float().requires_grad_(True)
+    h, g = xr.chunk(2, -1)
+    ref = h * F.gelu(g)
+    ref.backward(dy.float())
+    xg = x.to(dev()).requires_grad_(True)
+    y = GegluFn.apply(xg)
+    y.backward(dy.to(dev()))
+    close(y, ref, 2 ** -7, 1e-2, "geglu fwd")
+    assert rel_l2(xg.grad, xr.grad) < 6e-3
+    t = torch.randn(32, 1280)
+    tr = t.clone().requires_grad_(True)
+    F.silu(tr).backward(torch.ones_like(t))
+    tg = t.to(dev()).requires_grad_(True)
+    s = SiluF32ToBf16Fn.apply(tg)
+    s.backward(torch.ones_like(s))
+    close(s, F.silu(t), 2 ** -7, 1e-2, "silu")
+    close(tg.grad, tr.grad, 1e-4, 1e-5, "silu bwd")
+
+
+def test_timestep_embedding_and_layout():
+    from image_generator_amd import ops
+    t = torch.tensor([0.0, 1.0, 37.0, 999.0])
+    e = ops.timestep_embedding(t.to(dev()), 320)
+    half = 160
+    f = torch.exp(-math.log(10000.0) * torch.arange(half) / half)
+    ref = torch.cat([torch.cos(t[:, None] * f), torch.sin(t[:, None] * f)], -1)
+    close(e, ref, 2 ** -7, 2e-2, "timestep embedding")   # bf16 output; fp32 sin/cos of large arguments
+    x = torch.randn(2, 4, 5, 6)
+    y = ops.nchw_to_nhwc_bf16(x.to(dev()), 8)
+    assert torch.equal(y[..., :4].cpu(), x.permute(0, 2, 3, 1).to(BF)) and float(y[..., 4:].abs().max()) == 0.0
+    z = ops.ToNCHWFn.apply(y.float(), 4)
+    assert torch.equal(z.cpu(), x.to(BF).float())
+
+
+def test_mse_and_schedule_ops():
+    from image_generator_amd import ops
+    from image_generator_amd.ops import lib, check, _stream
+    from oracle import ops_ref
+    d = dev()
+    p, t = torch.randn(4, 4, 16, 16), torch.randn(4, 4, 16, 16)
+    pg = p.to(d).requires_grad_(True)
+    loss = ops.mse_loss(pg, t.to(d))
+    loss.backward()
+    pr = p.clone().requires_grad_(True)
+    lr = ops_ref.mse_loss(pr, t)
+    lr.backward()
+    close(loss, lr, 1e-5, 1e-6, "mse loss")
+    close(pg.grad, pr.grad, 1e-5, 1e-8, "mse grad")
+    acp = ops_ref.sd_alphas_cumprod()
+    ts = torch.tensor([0, 10, 500, 999])
+    out = torch.empty_like(p, device=d)
+    pd, td, tsd, acpd = p.to(d), t.to(d), ts.to(d), acp.to(d)     # keep every operand alive across the launch
+    check(lib.mi355_ddpm_add_noise(pd.data_ptr(), td.data_ptr(), tsd.data_ptr(), acpd.data_ptr(),
+                                   out.data_ptr(), 4, p[0].numel(), _stream()))
+    close(out, ops_ref.ddpm_add_noise(p, t, ts, acp), 1e-5, 1e-6, "add_noise")
+    eps = torch.randn(2, 4, 4, 16, 16)
+    x = torch.randn(4, 4, 16, 16)
+    tt, g = 481, 7.5
+    coef = torch.tensor([float(acp[tt]), float(acp[tt - 20]), g])
+    o = torch.empty_like(x, device=d)
+    epsd, xd, coefd = eps.to(d), x.to(d), coef.to(d)
+    check(lib.mi355_ddim_step_cfg(epsd.data_ptr(), xd.data_ptr(), o.data_ptr(), coefd.data_ptr(),
+                                  x.numel(), 1, _stream()))
+    e = ops_ref.cfg_combine(eps[0], eps[1], g)
+    close(o, ops_ref.ddim_step(e, tt, x, acp, 50), 2e-5, 2e-5, "ddim step")
+
+
+def test_adamw_matches_torch():
+    from image_generator_amd.ops import lib, check, _stream
+    d = dev()
+    n = 4096 + 8
+    p0, g = torch.randn(n), torch.randn(n) * 3
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-2, weight_decay=0.01)
+    p = p0.to(d)
+    m, v = torch.zeros(n, device=d), torch.zeros(n, device=d)
+    p16 = torch.empty(n, dtype=BF, device=d)
+    for step in range(1, 4):
+        pt.grad = g.clone() * step
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+        gg = (g * step).to(d)
+        state = torch.zeros(2, device=d)
+        check(lib.mi355_sumsq_f32(gg.data_ptr(), state.data_ptr(), n, _stream()))
+        hyper = torch.tensor([1e-2, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, 1.0, 1.0], device=d)
+        check(lib.mi355_adamw_step(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), p16.data_ptr(),
+                                   hyper.data_ptr(), state.data_ptr(), n, _stream()))
+    close(p, pt.detach(), 1e-5, 1e-6, "adamw")
+    assert torch.equal(p16.cpu(), p.cpu().to(BF))
+
+
+def test_contrastive_loss_golden(golden_dir):
+    """Fused InfoNCE against vectors minted from /root/reference/loss.py (fp32; tolerance 1e-4 rel)."""
+    import os
+    from image_generator_amd.loss import ContrastiveLoss
+    z = np.load(os.path.join(golden_dir, "contrastive.npz"))
+    for ci in range(4):
+        t = torch.tensor(z[f"c{ci}_t"]).to(dev()).requires_grad_(True)
+        i = torch.tensor(z[f"c{ci}_i"]).to(dev()).requires_grad_(True)
+        m = ContrastiveLoss().to(dev())
+        with torch.no_grad():
+            m.log_temp.copy_(torch.tensor(z[f"c{ci}_log_temp"]))
+        loss = m(t, i)
+        loss.backward()
+        scale = max(1.0, abs(float(z[f"c{ci}_loss"])))
+        close(loss, torch.tensor(z[f"c{ci}_loss"]), 2e-4, 2e-5 * scale, f"contrastive loss c{ci}")
+        for got, key in ((t.grad, "dt"), (i.grad, "di"), (m.log_temp.grad, "dlog_temp")):
+            ref = torch.tensor(z[f"c{ci}_{key}"])
+            close(got, ref, 2e-3, 2e-5 * max(1.0, float(ref.abs().max())), f"contrastive {key} c{ci}")
+
+
+def test_lora_linear_golden(golden_dir):
+    """LoRALinear forward/backward against vectors minted from /root/reference/lora.py.
+    The kernel computes in bf16 (fp32 accumulate): tolerance 2^-6 relative on y, 2% L2 on grads."""
+    import os
+    from image_generator_amd.lora import LoRALinear
+    z = np.load(os.path.join(golden_dir, "lora.npz"))
+    for ci in range(2):
+        w, b = torch.tensor(z[f"c{ci}_w"]), torch.tensor(z[f"c{ci}_b"])
+        lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=b.numel() > 0)
+        with torch.no_grad():
+            lin.weight.copy_(w)
+            if b.numel():
+                lin.bias.copy_(b)
+        m = LoRALinear(lin, r=4, alpha=float(z[f"c{ci}_alpha"])).to(dev())
+        with torch.no_grad():
+            m.lora_A.weight.copy_(torch.tensor(z[f"c{ci}_a"]))
+            m.lora_B.weight.copy_(torch.tensor(z[f"c{ci}_bb"]))
+        x = torch.tensor(z[f"c{ci}_x"]).to(dev()).requires_grad_(True)
+        y = m(x)
+        y.backward(torch.tensor(z[f"c{ci}_go"]).to(dev()))
+        ref_y = torch.tensor(z[f"c{ci}_y"])
+        close(y, ref_y, 2 ** -6, 3e-2, f"lora y c{ci}")
+        assert rel_l2(x.grad, torch.tensor(z[f"c{ci}_dx"])) < 2e-2
+        assert rel_l2(m.lora_A.weight.grad, torch.tensor(z[f"c{ci}_da"])) < 2e-2
+        assert rel_l2(m.lora_B.weight.grad, torch.tensor(z[f"c{ci}_db"])) < 2e-2
+        assert m.original.weight.grad is None
