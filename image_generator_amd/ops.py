@@ -148,10 +148,14 @@ class WeightPack:
     w16   : [N][K] bf16 (forward operand)
     w16_t : data-gradient operand: [K][N] for linear layers, [Cin][k][k][Cout] tap-flipped for convs.
     """
-    __slots__ = ("w16", "w16_t", "n", "k", "ksize", "cin", "cout", "cin_pad", "cout_pad")
+    __slots__ = ("w16", "w16_t", "n", "k", "ksize", "cin", "cout", "cin_pad", "cout_pad", "bias_pad", "grad_out",
+                 "on_grad_ready")
 
     def __init__(self):
         self.w16 = self.w16_t = None
+        self.bias_pad = None      # fp32 bias padded to cout_pad (convolutions whose Cout is not a multiple of 8)
+        self.grad_out = None      # optional fp32 [N][K] view the weight gradient is written into directly
+        self.on_grad_ready = None
 
 
 class LinearFn(torch.autograd.Function):
@@ -161,7 +165,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, pack, bias, residual, out_fp32, *weights):
         x2 = x.reshape(-1, x.shape[-1])
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
-        y = gemm(x2, pack.w16, bias=bias, residual=res2, out_fp32=out_fp32)
+        y = gemm(x2, pack.w16.view(pack.n, pack.k), bias=bias, residual=res2, out_fp32=out_fp32)
         ctx.save_for_backward(x2)
         ctx.pack = pack
         ctx.xshape = x.shape
@@ -181,19 +185,24 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy2.contiguous()
         dx = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(dy2, pack.w16_t).view(ctx.xshape)
+            dx = gemm(dy2, pack.w16_t.view(pack.k, pack.n)).view(ctx.xshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2)[0]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2.view(dy.shape)
         dws = [None] * len(ctx.wshapes)
         if any(ctx.wreq):
-            dw = wgrad(dy2, x2, pack.k, pack.n).view(pack.n, pack.k)
-            r0 = 0
-            for i, shp in enumerate(ctx.wshapes):
-                if ctx.wreq[i]:
-                    dws[i] = dw[r0:r0 + shp[0]]
-                r0 += shp[0]
+            if pack.grad_out is not None:
+                wgrad(dy2, x2, pack.k, pack.n, out=pack.grad_out)
+                if pack.on_grad_ready is not None:
+                    pack.on_grad_ready()
+            else:
+                dw = wgrad(dy2, x2, pack.k, pack.n).view(pack.n, pack.k)
+                r0 = 0
+                for i, shp in enumerate(ctx.wshapes):
+                    if ctx.wreq[i]:
+                        dws[i] = dw[r0:r0 + shp[0]].view(shp)
+                    r0 += shp[0]
         return (dx, None, db, dres, None, *dws)
 
 
@@ -203,7 +212,8 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, rowbias, residual, pack, stride, ups, out_fp32=False):
-        y = conv2d(x, pack.w16, pack.cout_pad, pack.ksize, stride=stride, ups=ups, bias=bias, rowbias=rowbias,
+        kb = bias if (bias is None or pack.bias_pad is None) else pack.bias_pad
+        y = conv2d(x, pack.w16, pack.cout_pad, pack.ksize, stride=stride, ups=ups, bias=kb, rowbias=rowbias,
                    residual=residual, out_fp32=out_fp32)
         ctx.save_for_backward(x)
         ctx.pack, ctx.stride, ctx.ups = pack, stride, ups
@@ -230,10 +240,16 @@ class ConvFn(torch.autograd.Function):
             else:
                 dx = dxv
         if ctx.wreq:
-            dwp = wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo))
-            dwp = dwp.view(pack.cout_pad, pack.ksize, pack.ksize, pack.cin_pad)
-            # logical OIHW view of the physical [O][kh][kw][I] buffer (channels_last), sliced to the true sizes
-            dw = dwp.permute(0, 3, 1, 2)[:pack.cout, :pack.cin]
+            if pack.grad_out is not None:
+                wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo),
+                      out=pack.grad_out)
+                if pack.on_grad_ready is not None:
+                    pack.on_grad_ready()
+            else:
+                dwp = wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo))
+                dwp = dwp.view(pack.cout_pad, pack.ksize, pack.ksize, pack.cin_pad)
+                # logical OIHW view of the physical [O][kh][kw][I] buffer (channels_last), sliced to the true sizes
+                dw = dwp.permute(0, 3, 1, 2)[:pack.cout, :pack.cin]
         dy2 = dy.view(-1, Co)
         if ctx.flags[0] and ctx.needs_input_grad[2]:
             db = colsum(dy2)[0][:pack.cout]
@@ -302,41 +318,42 @@ class LayerNormFn(torch.autograd.Function):
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(d)) v per head, no mask.
 
-    self-attention : qkv [B,N,3C] is the output of the fused q/k/v projection, kv is None;
-    cross-attention: q [B,N,C] and kv [B,T,2C] (fused k/v projection of the text embeddings).
-    The gradient comes back in the same fused layout, so no slicing/concatenation pass is needed.
+    Three operand layouts (the gradient comes back in the same layout, so fused projections need no
+    slicing / concatenation pass):
+      a = qkv [B,N,3C], b = c = None : output of the fused q/k/v projection (self-attention)
+      a = q [B,N,C], b = kv [B,T,2C], c = None : fused k/v projection of the text embeddings
+      a = q, b = k, c = v : three separate tensors
     """
 
     @staticmethod
-    def forward(ctx, q_src, kv_src, heads):
-        if kv_src is None:
-            C = q_src.shape[2] // 3
-            q, k, v = q_src[:, :, :C], q_src[:, :, C:2 * C], q_src[:, :, 2 * C:]
-        else:
-            C = q_src.shape[2]
-            q, k, v = q_src, kv_src[:, :, :C], kv_src[:, :, C:]
+    def _split(a, b, c):
+        if b is None:
+            C = a.shape[2] // 3
+            return a[:, :, :C], a[:, :, C:2 * C], a[:, :, 2 * C:]
+        if c is None:
+            C = a.shape[2]
+            return a, b[:, :, :C], b[:, :, C:]
+        return a, b, c
+
+    @staticmethod
+    def forward(ctx, a, b, c, heads):
+        q, k, v = AttentionFn._split(a, b, c)
         o, lse = attention_fwd(q, k, v, heads)
-        ctx.save_for_backward(q_src, kv_src, o, lse)
+        ctx.save_for_backward(a, b, c, o, lse)
         ctx.heads = heads
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q_src, kv_src, o, lse = ctx.saved_tensors
+        a, b, c, o, lse = ctx.saved_tensors
         do = do.contiguous()
-        dq_src = torch.empty_like(q_src)
-        if kv_src is None:
-            C = q_src.shape[2] // 3
-            q, k, v = q_src[:, :, :C], q_src[:, :, C:2 * C], q_src[:, :, 2 * C:]
-            dq, dk, dv = dq_src[:, :, :C], dq_src[:, :, C:2 * C], dq_src[:, :, 2 * C:]
-            dkv_src = None
-        else:
-            C = q_src.shape[2]
-            dkv_src = torch.empty_like(kv_src)
-            q, k, v = q_src, kv_src[:, :, :C], kv_src[:, :, C:]
-            dq, dk, dv = dq_src, dkv_src[:, :, :C], dkv_src[:, :, C:]
+        da = torch.empty_like(a)
+        db = None if b is None else torch.empty_like(b)
+        dc = None if c is None else torch.empty_like(c)
+        q, k, v = AttentionFn._split(a, b, c)
+        dq, dk, dv = AttentionFn._split(da, db, dc)
         attention_bwd(q, k, v, o, do, lse, ctx.heads, dq, dk, dv)
-        return dq_src, dkv_src, None
+        return da, db, dc, None
 
 
 class GegluFn(torch.autograd.Function):

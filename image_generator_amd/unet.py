@@ -1,0 +1,552 @@
+"""The text-conditioned denoiser on gfx950 kernels.
+
+Same call surface as the network the reference instantiates at
+/root/reference/generator/image_generator.py:27-29 and calls at :93-95 / :124:
+`unet(sample, timestep, encoder_hidden_states=...).sample`, `unet.config.in_channels`,
+`.parameters()`, `.state_dict()` (parameter names follow the public SD-v1 checkpoint layout).
+
+Design (MI355X-first, not a module-by-module translation):
+  * activations are bf16 NHWC / token-major end to end - GroupNorm, convolution and attention all
+    see C-contiguous rows and the (B,C,H,W)<->(B,HW,C) reshapes of the transformer wrapper are free;
+  * parameters are fp32 masters living in ONE flat buffer; a single cast kernel refreshes the flat
+    bf16 operand copy; because q/k/v (and cross-attention k/v) weights are adjacent in that buffer the
+    three projections run as one GEMM on a [3C][C] view;
+  * conv weights are stored [Cout][kh][kw][Cin] (torch channels_last for the OIHW parameter) which is
+    the K-contiguous operand of the implicit GEMM; the data-gradient operands (transposed,
+    tap-flipped) are refreshed once per optimizer step;
+  * bias, timestep-embedding broadcast and residual adds are fused into the GEMM epilogues.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from ._lib import lib, check
+from . import ops
+from .ops import (BF16, F32, AttentionFn, ConvFn, GegluFn, GroupNormFn, LayerNormFn, LinearFn, SiluF32ToBf16Fn,
+                  ToNCHWFn, ToNHWCFn, WeightPack, _stream)
+
+
+@dataclass
+class DenoiserConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Sequence[int] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    down_has_attn: Sequence[bool] = (True, True, True, False)
+    num_heads: int = 8
+    cross_attention_dim: int = 768
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    sample_size: int = 64
+
+    @staticmethod
+    def sd_v1() -> "DenoiserConfig":
+        return DenoiserConfig()
+
+    @staticmethod
+    def small() -> "DenoiserConfig":
+        return DenoiserConfig(block_out_channels=(64, 128, 128), layers_per_block=1,
+                              down_has_attn=(True, True, False), num_heads=4, cross_attention_dim=64,
+                              norm_num_groups=8, sample_size=8)
+
+    @property
+    def time_embed_dim(self) -> int:
+        return self.block_out_channels[0] * 4
+
+
+def _ceil8(n):
+    return (n + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------
+# leaf layers
+# ------------------------------------------------------------------------------------------------
+class HipLinear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+        self.pack = WeightPack()
+        self.pack.n, self.pack.k = out_features, in_features
+
+    def forward(self, x, residual=None, out_fp32=False):
+        return LinearFn.apply(x, self.pack, self.bias, residual, out_fp32, self.weight)
+
+
+class HipConv2d(nn.Module):
+    """weight is an OIHW parameter whose memory is [O][kh][kw][I] (channels_last)."""
+
+    def __init__(self, cin, cout, ksize, stride=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = cin, cout, ksize, stride
+        w = torch.empty(cout, cin, ksize, ksize)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        bound = 1 / math.sqrt(cin * ksize * ksize)
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        p = self.pack = WeightPack()
+        p.ksize, p.cin, p.cout, p.cin_pad, p.cout_pad = ksize, cin, cout, _ceil8(cin), _ceil8(cout)
+        p.n, p.k = p.cout_pad, ksize * ksize * p.cin_pad
+
+    @property
+    def padded(self):
+        return self.pack.cin != self.pack.cin_pad or self.pack.cout != self.pack.cout_pad
+
+    def forward(self, x, rowbias=None, residual=None, ups=False, out_fp32=False):
+        if self.kernel_size == 1 and self.stride == 1 and not self.padded:
+            return LinearFn.apply(x, self.pack, self.bias, residual, out_fp32, self.weight)
+        return ConvFn.apply(x, self.weight, self.bias, rowbias, residual, self.pack, self.stride, ups, out_fp32)
+
+
+class HipGroupNorm(nn.Module):
+    def __init__(self, groups, channels, eps):
+        super().__init__()
+        self.num_groups, self.eps = groups, eps
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x, silu):
+        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+
+
+class HipLayerNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# blocks
+# ------------------------------------------------------------------------------------------------
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.linear_1 = HipLinear(in_dim, out_dim)
+        self.linear_2 = HipLinear(out_dim, out_dim)
+
+    def forward(self, t_emb):
+        h = self.linear_1(t_emb, out_fp32=True)
+        return self.linear_2(SiluF32ToBf16Fn.apply(h), out_fp32=True)
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, cin, cout, temb_dim, groups, eps):
+        super().__init__()
+        self.norm1 = HipGroupNorm(groups, cin, eps)
+        self.conv1 = HipConv2d(cin, cout, 3)
+        self.time_emb_proj = HipLinear(temb_dim, cout)
+        self.norm2 = HipGroupNorm(groups, cout, eps)
+        self.conv2 = HipConv2d(cout, cout, 3)
+        self.conv_shortcut = HipConv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x, temb_act):
+        h = self.norm1(x, silu=True)
+        h = self.conv1(h, rowbias=self.time_emb_proj(temb_act, out_fp32=True))
+        h = self.norm2(h, silu=True)
+        res = x if self.conv_shortcut is None else self.conv_shortcut(x)
+        return self.conv2(h, residual=res)
+
+
+class Attention(nn.Module):
+    def __init__(self, query_dim, heads, context_dim=None):
+        super().__init__()
+        self.heads = heads
+        self.is_cross = context_dim is not None
+        context_dim = context_dim or query_dim
+        self.to_q = HipLinear(query_dim, query_dim, bias=False)
+        self.to_k = HipLinear(context_dim, query_dim, bias=False)
+        self.to_v = HipLinear(context_dim, query_dim, bias=False)
+        self.to_out = nn.ModuleList([HipLinear(query_dim, query_dim), nn.Identity()])
+        # fused projection operand (row-stacked adjacent weights), filled in by the owning UNet
+        self.fused_pack = WeightPack()
+        if self.is_cross:
+            self.fused_pack.n, self.fused_pack.k = 2 * query_dim, context_dim
+        else:
+            self.fused_pack.n, self.fused_pack.k = 3 * query_dim, query_dim
+
+    def _plain(self):
+        return all(isinstance(m, HipLinear) for m in (self.to_q, self.to_k, self.to_v))
+
+    def forward(self, x, context, residual):
+        if self._plain() and self.fused_pack.w16 is not None:
+            if self.is_cross:
+                q = self.to_q(x)
+                kv = LinearFn.apply(context, self.fused_pack, None, None, False, self.to_k.weight, self.to_v.weight)
+                a = AttentionFn.apply(q, kv, None, self.heads)
+            else:
+                qkv = LinearFn.apply(x, self.fused_pack, None, None, False, self.to_q.weight, self.to_k.weight,
+                                     self.to_v.weight)
+                a = AttentionFn.apply(qkv, None, None, self.heads)
+        else:   # adapters (LoRALinear) wrapped around the projections
+            src = context if self.is_cross else x
+            a = AttentionFn.apply(self.to_q(x).contiguous(), self.to_k(src).contiguous(), self.to_v(src).contiguous(),
+                                  self.heads)
+        out = self.to_out[0]
+        if isinstance(out, HipLinear):
+            return out(a, residual=residual)
+        return out(a) + residual
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = HipLinear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        return GegluFn.apply(self.proj(x))
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), HipLinear(dim * 4, dim)])
+
+    def forward(self, x, residual):
+        return self.net[2](self.net[0](x), residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, context_dim):
+        super().__init__()
+        self.norm1 = HipLayerNorm(dim)
+        self.attn1 = Attention(dim, heads)
+        self.norm2 = HipLayerNorm(dim)
+        self.attn2 = Attention(dim, heads, context_dim)
+        self.norm3 = HipLayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, context):
+        x = self.attn1(self.norm1(x), None, x)
+        x = self.attn2(self.norm2(x), context, x)
+        return self.ff(self.norm3(x), x)
+
+
+class Transformer2D(nn.Module):
+    def __init__(self, channels, heads, context_dim, groups):
+        super().__init__()
+        self.norm = HipGroupNorm(groups, channels, 1e-6)
+        self.proj_in = HipConv2d(channels, channels, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(channels, heads, context_dim)])
+        self.proj_out = HipConv2d(channels, channels, 1)
+
+    def forward(self, x, context):
+        B, H, W, C = x.shape
+        h = self.proj_in(self.norm(x, silu=False)).view(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        return self.proj_out(h.view(B, H, W, C), residual=x)
+
+
+class Downsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = HipConv2d(c, c, 3, stride=2)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample(nn.Module):
+    """nearest 2x upsample fused into the convolution's tile loader (never materialised)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv = HipConv2d(c, c, 3)
+
+    def forward(self, x):
+        return self.conv(x, ups=True)
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cfg, cin, cout, has_attn, add_down):
+        super().__init__()
+        self.resnets = nn.ModuleList()
+        self.attentions = nn.ModuleList() if has_attn else None
+        for j in range(cfg.layers_per_block):
+            self.resnets.append(ResnetBlock(cin if j == 0 else cout, cout, cfg.time_embed_dim, cfg.norm_num_groups,
+                                            cfg.norm_eps))
+            if has_attn:
+                self.attentions.append(Transformer2D(cout, cfg.num_heads, cfg.cross_attention_dim, cfg.norm_num_groups))
+        self.downsamplers = nn.ModuleList([Downsample(cout)]) if add_down else None
+
+    def forward(self, x, temb, ctx):
+        outs = []
+        for j, r in enumerate(self.resnets):
+            x = r(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[j](x, ctx)
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            outs.append(x)
+        return x, outs
+
+
+class MidBlock(nn.Module):
+    def __init__(self, cfg, c):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock(c, c, cfg.time_embed_dim, cfg.norm_num_groups, cfg.norm_eps)
+                                      for _ in range(2)])
+        self.attentions = nn.ModuleList([Transformer2D(c, cfg.num_heads, cfg.cross_attention_dim, cfg.norm_num_groups)])
+
+    def forward(self, x, temb, ctx):
+        x = self.resnets[0](x, temb)
+        x = self.attentions[0](x, ctx)
+        return self.resnets[1](x, temb)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cfg, cin, cout, cprev, has_attn, add_up):
+        super().__init__()
+        n = cfg.layers_per_block + 1
+        self.resnets = nn.ModuleList()
+        self.attentions = nn.ModuleList() if has_attn else None
+        for j in range(n):
+            skip = cin if j == n - 1 else cout
+            rin = cprev if j == 0 else cout
+            self.resnets.append(ResnetBlock(rin + skip, cout, cfg.time_embed_dim, cfg.norm_num_groups, cfg.norm_eps))
+            if has_attn:
+                self.attentions.append(Transformer2D(cout, cfg.num_heads, cfg.cross_attention_dim, cfg.norm_num_groups))
+        self.upsamplers = nn.ModuleList([Upsample(cout)]) if add_up else None
+
+    def forward(self, x, skips, temb, ctx):
+        for j, r in enumerate(self.resnets):
+            x = torch.cat([x, skips.pop()], dim=-1)
+            x = r(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[j](x, ctx)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class UNetOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, cfg: DenoiserConfig | None = None):
+        super().__init__()
+        cfg = cfg or DenoiserConfig.sd_v1()
+        self.config = cfg
+        ch = list(cfg.block_out_channels)
+        self.conv_in = HipConv2d(cfg.in_channels, ch[0], 3)
+        self.time_embedding = TimestepEmbedding(ch[0], cfg.time_embed_dim)
+        self.down_blocks = nn.ModuleList()
+        cout = ch[0]
+        for i, c in enumerate(ch):
+            cin, cout = cout, c
+            self.down_blocks.append(DownBlock(cfg, cin, cout, cfg.down_has_attn[i], i != len(ch) - 1))
+        self.mid_block = MidBlock(cfg, ch[-1])
+        self.up_blocks = nn.ModuleList()
+        rev, rev_attn = ch[::-1], list(cfg.down_has_attn)[::-1]
+        cout = rev[0]
+        for i, c in enumerate(rev):
+            cprev, cout = cout, c
+            cin = rev[min(i + 1, len(ch) - 1)]
+            self.up_blocks.append(UpBlock(cfg, cin, cout, cprev, rev_attn[i], i != len(ch) - 1))
+        self.conv_norm_out = HipGroupNorm(cfg.norm_num_groups, ch[0], cfg.norm_eps)
+        self.conv_out = HipConv2d(ch[0], cfg.out_channels, 3)
+        # flat-buffer state (built lazily on the device the parameters live on)
+        self._flat = None
+        self._flat16 = None
+        self._flat_grad = None
+        self._layout = None
+        self._sig = None
+
+    # -------------------------------------------------------------------------------------------
+    # flat parameter storage and bf16 operand copies
+    # -------------------------------------------------------------------------------------------
+    def _gemm_weight_ids(self):
+        ids = set()
+        for m in self.modules():
+            if isinstance(m, (HipLinear, HipConv2d)):
+                ids.add(id(m.weight))
+        return ids
+
+    def _build_flat(self):
+        params = list(self.parameters())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("UNet2DConditionModel: parameters must live on the HIP device (no CPU path)")
+        wid = self._gemm_weight_ids()
+        big = [p for p in params if id(p) in wid]
+        small = [p for p in params if id(p) not in wid]
+        offs, off = {}, 0
+        for p in big + small:
+            offs[id(p)] = off
+            off += _ceil8(p.numel())
+        self._n_big = sum(_ceil8(p.numel()) for p in big)
+        flat = torch.zeros(off, dtype=F32, device=dev)
+        for p in big + small:
+            o, n = offs[id(p)], p.numel()
+            if p.dim() == 4:
+                co, ci, kh, kw = p.shape
+                view = flat[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            else:
+                view = flat[o:o + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+        self._flat, self._offs = flat, offs
+        self._flat16 = torch.zeros(off, dtype=BF16, device=dev)
+        self._flat_grad = None
+        # operand packs
+        self._packs = []
+        for m in self.modules():
+            if isinstance(m, HipLinear):
+                pk, o = m.pack, offs[id(m.weight)]
+                pk.w16 = self._flat16[o:o + pk.n * pk.k].view(pk.n, pk.k)
+                pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
+                self._packs.append(("linear", m, pk, o))
+            elif isinstance(m, HipConv2d):
+                pk, o = m.pack, offs[id(m.weight)]
+                t = pk.ksize * pk.ksize
+                if m.padded:
+                    pk.w16 = torch.zeros((pk.cout_pad, t, pk.cin_pad), dtype=BF16, device=dev)
+                    pk.bias_pad = torch.zeros(pk.cout_pad, dtype=F32, device=dev)
+                else:
+                    pk.w16 = self._flat16[o:o + pk.cout * t * pk.cin].view(pk.cout, t, pk.cin)
+                pk.w16_t = torch.empty((pk.cin_pad, t, pk.cout_pad), dtype=BF16, device=dev)
+                self._packs.append(("conv", m, pk, o))
+        for m in self.modules():
+            if isinstance(m, Attention):
+                pk = m.fused_pack
+                ws = [m.to_k, m.to_v] if m.is_cross else [m.to_q, m.to_k, m.to_v]
+                if not all(isinstance(w, HipLinear) for w in ws):
+                    pk.w16 = None
+                    continue
+                o0 = offs[id(ws[0].weight)]
+                adjacent = all(offs[id(ws[i + 1].weight)] == offs[id(ws[i].weight)] + ws[i].weight.numel()
+                               for i in range(len(ws) - 1))
+                if not adjacent:
+                    pk.w16 = None
+                    continue
+                pk.w16 = self._flat16[o0:o0 + pk.n * pk.k].view(pk.n, pk.k)
+                pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
+                self._packs.append(("fused", m, pk, o0))
+        self._layout = (dev, params[0].data_ptr())
+        self._sig = None
+
+    def _ensure_flat(self):
+        p0 = next(self.parameters())
+        if self._flat is None or self._layout != (p0.device, p0.data_ptr()):
+            self._build_flat()
+
+    def _signature(self):
+        return tuple(p._version for p in self.parameters())
+
+    def refresh_operands(self, cast=True):
+        """Re-derive every bf16 operand from the fp32 masters (call after the parameters changed)."""
+        self._ensure_flat()
+        s = _stream()
+        if cast:
+            check(lib.mi355_cast_f32_to_bf16(self._flat.data_ptr(), self._flat16.data_ptr(), self._flat.numel(), s), "cast")
+        for kind, m, pk, o in self._packs:
+            if kind in ("linear", "fused"):
+                check(lib.mi355_transpose_bf16(pk.w16.data_ptr(), pk.w16_t.data_ptr(), 1, pk.n, pk.k, s), "transpose")
+            else:
+                t = pk.ksize * pk.ksize
+                if m.padded:
+                    phys = m.weight.data.permute(0, 2, 3, 1).reshape(pk.cout, t, pk.cin)
+                    pk.w16[:pk.cout, :, :pk.cin] = phys.to(BF16)
+                    pk.bias_pad[:pk.cout] = m.bias.data
+                check(lib.mi355_conv_weight_transpose(pk.w16.data_ptr(), pk.w16_t.data_ptr(), pk.cout_pad, t, pk.cin_pad, s),
+                      "conv_weight_transpose")
+        self._sig = self._signature()
+
+    def _maybe_refresh(self):
+        self._ensure_flat()
+        if self._sig != self._signature():
+            self.refresh_operands()
+
+    def operands_current(self):
+        """Tell the module its bf16 copies already match the masters (fused optimizer wrote both)."""
+        self._sig = self._signature()
+
+    def flat_parameters(self):
+        self._ensure_flat()
+        return self._flat, self._flat16
+
+    def enable_direct_grads(self):
+        """Weight gradients of all GEMM layers are written straight into one flat fp32 buffer
+        (`param.grad` are views of it); small parameters accumulate into its tail through autograd."""
+        self._ensure_flat()
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+        g = self._flat_grad
+        for p in self.parameters():
+            o, n = self._offs[id(p)], p.numel()
+            if p.dim() == 4:
+                co, ci, kh, kw = p.shape
+                p.grad = g[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            else:
+                p.grad = g[o:o + n].view(p.shape)
+        fused_members = set()
+        for kind, m, pk, o in self._packs:
+            if kind == "fused":
+                pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
+                for w in ([m.to_k, m.to_v] if m.is_cross else [m.to_q, m.to_k, m.to_v]):
+                    fused_members.add(id(w))
+        for kind, m, pk, o in self._packs:
+            if kind == "linear":
+                pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
+            elif kind == "conv" and not m.padded:
+                pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
+        return g
+
+    def zero_small_grads(self):
+        if self._flat_grad is not None:
+            self._flat_grad[self._n_big:].zero_()
+            for kind, m, pk, o in self._packs:
+                if kind == "conv" and m.padded:
+                    n = m.weight.numel()
+                    self._flat_grad[o:o + n].zero_()
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, sample, timestep, encoder_hidden_states=None):
+        if not sample.is_cuda:
+            raise RuntimeError("UNet2DConditionModel: HIP device tensors required (no CPU path)")
+        self._maybe_refresh()
+        cfg = self.config
+        B = sample.shape[0]
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], device=sample.device)
+        t = timestep.to(device=sample.device, dtype=F32).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B)
+        t = t.contiguous()
+        t_emb = ops.timestep_embedding(t, cfg.block_out_channels[0])
+        emb = self.time_embedding(t_emb)                 # [B, 4*C0] fp32
+        temb_act = SiluF32ToBf16Fn.apply(emb)            # shared by every residual block
+        ctx = encoder_hidden_states
+        if ctx.dtype != BF16:
+            ctx = ctx.to(BF16)
+        ctx = ctx.contiguous()
+        x = ToNHWCFn.apply(sample, self.conv_in.pack.cin_pad)
+        x = self.conv_in(x)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, temb_act, ctx)
+            skips.extend(outs)
+        x = self.mid_block(x, temb_act, ctx)
+        for blk in self.up_blocks:
+            x = blk(x, skips, temb_act, ctx)
+        x = self.conv_norm_out(x, silu=True)
+        x = self.conv_out(x, out_fp32=True)
+        return UNetOutput(ToNCHWFn.apply(x, cfg.out_channels))

@@ -221,7 +221,7 @@ def test_self_attention(B, H, N, D):
     ref = _attn_ref(r[..., :C], r[..., C:2 * C], r[..., 2 * C:], H)
     ref.backward(do.float())
     g = qkv.to(dev()).requires_grad_(True)
-    o = AttentionFn.apply(g, None, H)
+    o = AttentionFn.apply(g, None, None, H)
     o.backward(do.to(dev()))
     close(o, ref, 2 ** -6, 1e-2, "attn fwd")
     assert rel_l2(o, ref) < 6e-3
@@ -237,7 +237,7 @@ def test_cross_attention(B, H, N, T, D):
     ref = _attn_ref(qr, kvr[..., :C], kvr[..., C:], H)
     ref.backward(do.float())
     qg, kvg = q.to(dev()).requires_grad_(True), kv.to(dev()).requires_grad_(True)
-    o = AttentionFn.apply(qg, kvg, H)
+    o = AttentionFn.apply(qg, kvg, None, H)
     o.backward(do.to(dev()))
     close(o, ref, 2 ** -6, 1e-2, "xattn fwd")
     assert rel_l2(qg.grad, qr.grad) < 1.5e-2, rel_l2(qg.grad, qr.grad)
@@ -254,7 +254,7 @@ def test_attention_softmax_spike():
     qkv = qkv.to(BF)
     r = qkv.float()
     ref = _attn_ref(r[..., :C], r[..., C:2 * C], r[..., 2 * C:], H)
-    o = AttentionFn.apply(qkv.to(dev()), None, H)
+    o = AttentionFn.apply(qkv.to(dev()), None, None, H)
     close(o, ref, 2 ** -6, 1e-2, "attn spike")
 
 
