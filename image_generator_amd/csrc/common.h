@@ -58,6 +58,19 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+// out[s][n] = sum_r partial[s][r][n]; launch with grid (ceil(N/64), nseg), 256 threads (64 columns x 4 row phases).
+// (static: every translation unit that launches it carries its own copy; no relocatable device code needed)
+static __global__ void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int R, int N) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6, s = blockIdx.y;
+    float acc = 0.f;
+    if (col < N)
+        for (int r = ph; r < R; r += 4) acc += partial[((size_t)s * R + r) * N + col];
+    red[ph][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ph == 0 && col < N) out[(size_t)s * N + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // Blocks that share an XCD (ids congruent mod 8) get one contiguous chunk of the logical grid.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;

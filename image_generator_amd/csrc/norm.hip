@@ -18,7 +18,7 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 }
 
 // MODE 0: acc0 += x, acc1 += x^2.   MODE 1: dz = dy * act'(z); acc0 += dz, acc1 += dz * xhat.
-// grid = (strips, B); blockDim.x = nc * rows_par (nc = C/8).  sums: [B][C][2] fp32, pre-zeroed.
+// grid = (strips, B); blockDim.x = nc * rows_par (nc = C/8).  sums: per-strip partials [B][strips][C][2] fp32.
 template <int MODE>
 __global__ void gn_chan_sums_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                     const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -72,10 +72,23 @@ __global__ void gn_chan_sums_kernel(const bf16_t* __restrict__ x, const bf16_t* 
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a0[e] += o[e]; a1[e] += o[8 + e]; }
         }
-        float* dst = sums + ((size_t)b * C + c8 * 8) * 2;
+        // per-strip partial (plain stores; a second kernel sums the strips - no contended atomics)
+        float* dst = sums + (((size_t)b * gridDim.x + blockIdx.x) * C + c8 * 8) * 2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(dst + 2 * e, a0[e]); atomicAdd(dst + 2 * e + 1, a1[e]); }
+        for (int e = 0; e < 8; e += 2)
+            *(f32x4*)(dst + 2 * e) = f32x4{a0[e], a1[e], a0[e + 1], a1[e + 1]};
     }
+}
+
+// sums[b][c][k] = sum over strips of partial[b][strip][c][k]   (one thread per (b, c, k))
+__global__ void gn_reduce_strips_kernel(const float* __restrict__ partial, float* __restrict__ sums, int B, int C,
+                                        int strips) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C * 2) return;
+    const int b = i / (C * 2), r = i - b * C * 2;
+    float s = 0.f;
+    for (int t = 0; t < strips; ++t) s += partial[((size_t)b * strips + t) * C * 2 + r];
+    sums[i] = s;
 }
 
 // one thread per (b, g)
@@ -241,8 +254,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 // dx per row; dgamma/dbeta partials kept in registers across the rows a wave visits, combined by atomics.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     bf16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int C) {
+                                                     bf16_t* __restrict__ dx, float* __restrict__ partial,
+                                                     int M, int C) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nc = C >> 3;
@@ -290,16 +303,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             }
         }
     }
+    // combine the block's waves through LDS, then one partial row per block: partial[block][2][C]
+    extern __shared__ float lred[];      // [wpb][2][C]
+    const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < LN_MAXCH; ++k) {
         const int c8 = lane + 64 * k;
         if (c8 < nc) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                atomicAdd(dgamma + c8 * 8 + e, pg[k][e]);
-                atomicAdd(dbeta + c8 * 8 + e, pb[k][e]);
+                lred[((size_t)w * 2) * C + c8 * 8 + e] = pg[k][e];
+                lred[((size_t)w * 2 + 1) * C + c8 * 8 + e] = pb[k][e];
             }
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float sacc = 0.f;
+        for (int q = 0; q < wpb; ++q) sacc += lred[(size_t)q * 2 * C + i];
+        partial[(size_t)blockIdx.x * 2 * C + i] = sacc;
     }
 }
 
@@ -321,26 +343,34 @@ static int gn_geometry(int HW, int C, int G, int* threads, int* rpar, int* rows_
 
 extern "C" {
 
-// scratch: B*C*2 floats.  stats out: [B][G][2] = mean, rstd.
+// scratch floats needed by the two GroupNorm calls for a [B][HW][C] tensor with G groups.
+long long mi355_groupnorm_scratch_floats(int B, int HW, int C, int G) {
+    int threads, rpar, rows, strips;
+    if (gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return -1;
+    return (long long)B * strips * C * 2 + (long long)B * C * 2 + (long long)B * G * 2;
+}
+
+// scratch: mi355_groupnorm_scratch_floats().  stats out: [B][G][2] = mean, rstd.
 int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* scratch,
                         int B, int HW, int C, int G, float eps, int silu, void* stream) {
     if (!x || !gamma || !beta || !y || !stats || !scratch) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd: null pointer");
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scratch, 0, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess)
-        return mi355_fail(MI355_ERR_LAUNCH, "groupnorm_fwd: memset failed");
+    float* partial = scratch;
+    float* sums = scratch + (size_t)B * strips * C * 2;
     ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 3);
     const size_t sh = (size_t)threads * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_chan_sums_kernel<0>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x, nullptr,
-                       nullptr, nullptr, nullptr, scratch, HW, C, G, rows, 0);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, scratch, stats, B, C, G, HW, eps);
+                       nullptr, nullptr, nullptr, partial, HW, C, G, rows, 0);
+    hipLaunchKernelGGL(gn_reduce_strips_kernel, dim3((B * C * 2 + 255) / 256), dim3(256), 0, st, partial, sums, B, C, strips);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, sums, stats, B, C, G, HW, eps);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(strips, B), dim3(threads), 0, st, (const bf16_t*)x, stats, gamma, beta,
                        (bf16_t*)y, HW, C, G, rows, silu);
     return mi355_check_launch("groupnorm_fwd");
 }
 
-// scratch: B*C*2 + B*G*2 floats.
+// scratch: mi355_groupnorm_scratch_floats().
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
                         void* stream) {
@@ -349,14 +379,14 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    float* sums = scratch;
-    float* gsum = scratch + (size_t)B * C * 2;
-    if (hipMemsetAsync(sums, 0, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess)
-        return mi355_fail(MI355_ERR_LAUNCH, "groupnorm_bwd: memset failed");
+    float* partial = scratch;
+    float* sums = scratch + (size_t)B * strips * C * 2;
+    float* gsum = sums + (size_t)B * C * 2;
     ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 5);
     const size_t sh = (size_t)threads * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_chan_sums_kernel<1>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x,
-                       (const bf16_t*)dy, stats, gamma, beta, sums, HW, C, G, rows, silu);
+                       (const bf16_t*)dy, stats, gamma, beta, partial, HW, C, G, rows, silu);
+    hipLaunchKernelGGL(gn_reduce_strips_kernel, dim3((B * C * 2 + 255) / 256), dim3(256), 0, st, partial, sums, B, C, strips);
     const int nfin = B * G > C ? B * G : C;
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nfin + 255) / 256), dim3(256), 0, st, sums, gamma, gsum, dgamma,
                        dbeta, B, C, G);
@@ -377,20 +407,25 @@ int mi355_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
     return mi355_check_launch("layernorm_fwd");
 }
 
-// dgamma/dbeta are overwritten (zeroed here, then accumulated by atomics).
+static int ln_bwd_grid(int M) {
+    int grid = (M + 3) / 4;
+    return grid > 256 ? 256 : grid;
+}
+long long mi355_layernorm_bwd_scratch_floats(int M, int C) { return (long long)ln_bwd_grid(M) * 2 * C; }
+
+// dgamma_dbeta: [2][C] floats (dgamma row, then dbeta row), overwritten.
+// scratch: mi355_layernorm_bwd_scratch_floats().
 int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx,
-                        float* dgamma, float* dbeta, int M, int C, void* stream) {
-    if (!x || !dy || !stats || !gamma || !dx || !dgamma || !dbeta) return mi355_fail(MI355_ERR_ARG, "layernorm_bwd: null pointer");
+                        float* dgamma_dbeta, float* scratch, int M, int C, void* stream) {
+    if (!x || !dy || !stats || !gamma || !dx || !dgamma_dbeta || !scratch)
+        return mi355_fail(MI355_ERR_ARG, "layernorm_bwd: null pointer");
     if (C % 8 || C > 8 * 64 * LN_MAXCH) return mi355_fail(MI355_ERR_UNSUPPORTED, "layernorm: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), st) != hipSuccess)
-        return mi355_fail(MI355_ERR_LAUNCH, "layernorm_bwd: memset failed");
-    int grid = (M + 3) / 4;
-    if (grid > 512) grid = 512;
+    const int grid = ln_bwd_grid(M);
     ProfScope prof(FAM_NORM, st, (double)M * C * 2 * 3);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma,
-                       (bf16_t*)dx, dgamma, dbeta, M, C);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * 2 * C * sizeof(float), st, (const bf16_t*)x,
+                       (const bf16_t*)dy, stats, gamma, (bf16_t*)dx, scratch, M, C);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, scratch, dgamma_dbeta, grid, 2 * C);
     return mi355_check_launch("layernorm_bwd");
 }
 

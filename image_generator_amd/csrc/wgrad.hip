@@ -151,32 +151,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
 
 // Column sums of a bf16 matrix in segments of `seg` rows: out[s][n] = sum_{m in segment s} y[m][n].
 // Used for bias gradients (one segment) and the timestep-embedding broadcast gradient (one segment
-// per sample).  fp32 atomics combine the row-chunks of a segment; `out` must be zeroed by the caller.
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ y, float* __restrict__ out, int M,
-                                                     int N, int seg, int rows_per_block) {
+// per sample).  Two stages without atomics: each block reduces a strip of rows to one partial row
+// (row phases combined through LDS), a second kernel sums the partial rows of every segment.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ y, float* __restrict__ partial,
+                                                             int M, int N, int seg, int rows_per_block,
+                                                             int chunks_per_seg) {
+    extern __shared__ float cred[];      // [rphase][N]
     const int nc = N / 8;
-    const int chunks_per_seg = (seg + rows_per_block - 1) / rows_per_block;
     const int s = blockIdx.x / chunks_per_seg, ck = blockIdx.x - s * chunks_per_seg;
     const int r_begin = s * seg + ck * rows_per_block;
     int r_end = r_begin + rows_per_block;
     if (r_end > (s + 1) * seg) r_end = (s + 1) * seg;
     if (r_end > M) r_end = M;
-    // thread -> column chunk (tid % nc8) with row phase (tid / nc8)
-    const int cpb = nc < 256 ? nc : 256;         // column chunks handled concurrently
+    const int cpb = nc < 256 ? nc : 256;
     const int rphase = 256 / cpb;
+    const int rp = threadIdx.x / cpb;
     for (int c0 = 0; c0 < nc; c0 += cpb) {
         const int c = c0 + (threadIdx.x % cpb);
-        const int rp = threadIdx.x / cpb;
-        if (c >= nc || rp >= rphase) continue;
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r = r_begin + rp; r < r_end; r += rphase) {
-            const bf16x8 t = *(const bf16x8*)(y + (size_t)r * N + c * 8);
+        if (c < nc && rp < rphase) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = r_begin + rp; r < r_end; r += rphase) {
+                const bf16x8 t = *(const bf16x8*)(y + (size_t)r * N + c * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cred[(size_t)rp * N + c * 8 + e] = v[e];
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) unsafeAtomicAdd(out + (size_t)s * N + c * 8 + e, v[e]);
     }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float a = 0.f;
+        for (int q = 0; q < rphase; ++q) a += cred[(size_t)q * N + n];
+        partial[(size_t)blockIdx.x * N + n] = a;
+    }
+}
+static void colsum_geometry(int M, int N, int seg, int* rows_per_block, int* chunks) {
+    const int nseg = M / seg;
+    int target = 256 / nseg;            // about one block per CU in total
+    if (target < 1) target = 1;
+    int rows = (seg + target - 1) / target;
+    if (rows < 16) rows = 16;
+    if (rows > seg) rows = seg;
+    *rows_per_block = rows;
+    *chunks = (seg + rows - 1) / rows;
 }
 
 extern "C" {
@@ -211,20 +229,27 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int
     return mi355_check_launch("wgrad_kernel");
 }
 
-int mi355_colsum_bf16(const void* y, float* out, int M, int N, int seg, void* stream) {
-    if (!y || !out) return mi355_fail(MI355_ERR_ARG, "colsum: null pointer");
+long long mi355_colsum_scratch_floats(int M, int N, int seg) {
+    if (seg <= 0 || M % seg) return -1;
+    int rows, chunks;
+    colsum_geometry(M, N, seg, &rows, &chunks);
+    return (long long)(M / seg) * chunks * N;
+}
+
+int mi355_colsum_bf16(const void* y, float* out, float* scratch, int M, int N, int seg, void* stream) {
+    if (!y || !out || !scratch) return mi355_fail(MI355_ERR_ARG, "colsum: null pointer");
     if ((N & 7) || seg <= 0 || M % seg) return mi355_fail(MI355_ERR_ARG, "colsum: N %% 8 == 0 and M %% seg == 0 required");
+    const int nc = N / 8, cpb = nc < 256 ? nc : 256, rphase = 256 / cpb;
+    if ((size_t)rphase * N * sizeof(float) > 64 * 1024) return mi355_fail(MI355_ERR_UNSUPPORTED, "colsum: N=%d too large", N);
     hipStream_t st = (hipStream_t)stream;
     const int nseg = M / seg;
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)nseg * N * sizeof(float), st);
-    if (e != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "colsum: memset failed: %s", hipGetErrorString(e));
-    int rows_per_block = 256;
-    if (rows_per_block > seg) rows_per_block = seg;
-    const int chunks = (seg + rows_per_block - 1) / rows_per_block;
+    int rows, chunks;
+    colsum_geometry(M, N, seg, &rows, &chunks);
     ProfScope prof(FAM_ELEM, st, (double)M * N * 2);
-    hipLaunchKernelGGL(colsum_kernel, dim3(nseg * chunks), dim3(256), 0, st, (const bf16_t*)y, out, M, N, seg,
-                       rows_per_block);
-    return mi355_check_launch("colsum_kernel");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nseg * chunks), dim3(256), (size_t)rphase * N * sizeof(float), st,
+                       (const bf16_t*)y, scratch, M, N, seg, rows, chunks);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64, nseg), dim3(256), 0, st, scratch, out, chunks, N);
+    return mi355_check_launch("colsum");
 }
 
 }  // extern "C"

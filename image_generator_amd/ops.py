@@ -102,7 +102,8 @@ def colsum(y2d, seg=None):
     M, N = y2d.shape
     seg = M if seg is None else seg
     out = torch.empty((M // seg, N), dtype=F32, device=y2d.device)
-    check(lib.mi355_colsum_bf16(y2d.data_ptr(), out.data_ptr(), M, N, seg, _stream()), "colsum")
+    scratch = torch.empty(int(lib.mi355_colsum_scratch_floats(M, N, seg)), dtype=F32, device=y2d.device)
+    check(lib.mi355_colsum_bf16(y2d.data_ptr(), out.data_ptr(), scratch.data_ptr(), M, N, seg, _stream()), "colsum")
     return out
 
 
@@ -266,7 +267,7 @@ class GroupNormFn(torch.autograd.Function):
         B, H, W, C = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((B, groups, 2), dtype=F32, device=x.device)
-        scratch = torch.empty((B * C * 2,), dtype=F32, device=x.device)
+        scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, groups)), dtype=F32, device=x.device)
         check(lib.mi355_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                       scratch.data_ptr(), B, H * W, C, groups, eps, int(silu), _stream()), "groupnorm_fwd")
         ctx.save_for_backward(x, stats, gamma, beta)
@@ -282,7 +283,7 @@ class GroupNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty_like(gamma)
         db = torch.empty_like(beta)
-        scratch = torch.empty((B * C * 2 + B * G * 2,), dtype=F32, device=x.device)
+        scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, G)), dtype=F32, device=x.device)
         check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                       dx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), B, H * W, C, G,
                                       int(ctx.silu), _stream()), "groupnorm_bwd")
@@ -308,11 +309,11 @@ class LayerNormFn(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(gamma)
+        dgb = torch.empty((2, C), dtype=F32, device=x.device)
+        scratch = torch.empty(int(lib.mi355_layernorm_bwd_scratch_floats(M, C)), dtype=F32, device=x.device)
         check(lib.mi355_layernorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                                      dg.data_ptr(), db.data_ptr(), M, C, _stream()), "layernorm_bwd")
-        return dx, dg, db, None
+                                      dgb.data_ptr(), scratch.data_ptr(), M, C, _stream()), "layernorm_bwd")
+        return dx, dgb[0], dgb[1], None
 
 
 class AttentionFn(torch.autograd.Function):

@@ -503,11 +503,13 @@ class UNet2DConditionModel(nn.Module):
                 pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
                 for w in ([m.to_k, m.to_v] if m.is_cross else [m.to_q, m.to_k, m.to_v]):
                     fused_members.add(id(w))
+        self._grad_packs = []          # (offset, numel, pack) of every layer whose backward writes into `g`
         for kind, m, pk, o in self._packs:
-            if kind == "linear":
-                pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
-            elif kind == "conv" and not m.padded:
-                pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
+            if kind == "conv" and m.padded:
+                continue
+            pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
+            if kind == "fused" or id(m) not in fused_members:
+                self._grad_packs.append((o, pk.n * pk.k, pk))
         return g
 
     def zero_small_grads(self):

@@ -68,7 +68,8 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int
                      int stride, int ups, int Ho, int Wo, int accumulate, void* stream);
 
 /* out[s][n] = sum of the rows of segment s (seg rows each) of y[M][N] (bias / broadcast gradients). */
-int mi355_colsum_bf16(const void* y, float* out, int M, int N, int seg, void* stream);
+long long mi355_colsum_scratch_floats(int M, int N, int seg);
+int mi355_colsum_bf16(const void* y, float* out, float* scratch, int M, int N, int seg, void* stream);
 
 /* ---- attention (self- and cross-attention of the transformer blocks) ---------------------------
  * q [B][Nq][H*D] (row stride ldq), k/v [B][Nk][H*D] (ldk, ldv), out [B][Nq][H*D] (ldo); no mask
@@ -81,7 +82,8 @@ int mi355_attention_bwd(const void* q, const void* k, const void* v, const void*
 
 /* ---- normalisation ------------------------------------------------------------------------------
  * GroupNorm over [B][HW][C] with G groups, optional fused SiLU.  stats [B][G][2] = (mean, rstd).
- * fwd scratch: B*C*2 floats; bwd scratch: B*C*2 + B*G*2 floats. */
+ * scratch (both calls): mi355_groupnorm_scratch_floats(B, HW, C, G) floats. */
+long long mi355_groupnorm_scratch_floats(int B, int HW, int C, int G);
 int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* scratch,
                         int B, int HW, int C, int G, float eps, int silu, void* stream);
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
@@ -90,8 +92,10 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
 /* LayerNorm over rows of [M][C]; stats [M][2] = (mean, rstd). */
 int mi355_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C,
                         float eps, void* stream);
+long long mi355_layernorm_bwd_scratch_floats(int M, int C);
+/* dgamma_dbeta: [2][C] floats (dgamma row, then dbeta row). */
 int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx,
-                        float* dgamma, float* dbeta, int M, int C, void* stream);
+                        float* dgamma_dbeta, float* scratch, int M, int C, void* stream);
 
 /* ---- elementwise / layout -----------------------------------------------------------------------*/
 int mi355_geglu_fwd(const void* in, void* out, long long M, int F, void* stream);           /* in [M][2F] */
