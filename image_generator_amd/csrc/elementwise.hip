@@ -117,6 +117,52 @@ __global__ void conv_weight_transpose_kernel(const bf16_t* __restrict__ w, bf16_
         if (co < Co && ci < Ci) wt[((size_t)ci * T + (T - 1 - tap)) * Co + co] = tile[tx][k];
     }
 }
+// All per-step weight transposes in one launch: job j covers tiles [first_j, first_{j+1}); each tile is a
+// 64x64 block of one tap plane.  src [R][T][C] -> dst [C][T-1-t][R].
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const long long* __restrict__ jobs, int njobs) {
+    __shared__ bf16_t tile[64][72];
+    __shared__ int sjob;
+    const int bid = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[(size_t)mid * 6 + 5] <= bid) lo = mid; else hi = mid - 1;
+        }
+        sjob = lo;
+    }
+    __syncthreads();
+    const long long* J = jobs + (size_t)sjob * 6;
+    const bf16_t* src = (const bf16_t*)J[0];
+    bf16_t* dst = (bf16_t*)J[1];
+    const int R = (int)J[2], C = (int)J[3], T = (int)J[4];
+    int t = bid - (int)J[5];
+    const int tc = (C + 63) / 64, tr = (R + 63) / 64;
+    const int c0 = (t % tc) * 64; t /= tc;
+    const int r0 = (t % tr) * 64;
+    const int tap = t / tr;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int lr = threadIdx.x >> 3, lc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = r0 + lr + 32 * h, c = c0 + lc;
+        bf16x8 v = zero8;
+        if (r < R && c < C) v = *(const bf16x8*)(src + ((size_t)r * T + tap) * C + c);   // C % 8 == 0
+        *(bf16x8*)(&tile[lr + 32 * h][lc]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = c0 + lr + 32 * h, r = r0 + lc;
+        if (c < C && r < R) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[lc + e][lr + 32 * h];
+            *(bf16x8*)(dst + ((size_t)c * T + (T - 1 - tap)) * R + r) = v;                 // R % 8 == 0
+        }
+    }
+}
+
 // NCHW fp32 [B][Cs][HW] -> NHWC bf16 [B][HW][Cd] (channels >= Cs zero padded)
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int Cs, int Cd, int HW) {
     const size_t total = (size_t)B * HW * Cd;
@@ -478,6 +524,12 @@ int mi355_conv_weight_transpose(const void* w, void* wt, int Co, int taps, int C
     ProfScope prof(FAM_ELEM, ST, (double)Co * taps * Ci * 4);
     hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32, taps), dim3(256), 0, ST, (const bf16_t*)w, (bf16_t*)wt, Co, taps, Ci);
     return mi355_check_launch("conv_weight_transpose");
+}
+int mi355_transpose_batched(const long long* jobs, int njobs, int total_tiles, void* stream) {
+    if (!jobs || njobs <= 0 || total_tiles <= 0) return mi355_fail(MI355_ERR_ARG, "transpose_batched: bad arguments");
+    ProfScope prof(FAM_ELEM, ST, (double)total_tiles * 64 * 64 * 4);
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, ST, jobs, njobs);
+    return mi355_check_launch("transpose_batched");
 }
 int mi355_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int Cs, int Cd, int HW, void* stream) {
     if (!x || !y || Cd < Cs) return mi355_fail(MI355_ERR_ARG, "nchw_to_nhwc: bad arguments");

@@ -14,6 +14,7 @@
 // The epilogue stages fp32 accumulators through LDS so that bias / broadcast row bias (timestep
 // embedding) / LoRA rank-r update / residual are applied with 16-byte coalesced accesses.
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvGeom {
     int B, H, W, C;   // stored NHWC input
@@ -346,12 +347,25 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
     return mi355_check_launch("gemm_kernel");
 }
 
-static int pick_splitk(int tiles, int nkt) {
-    if (tiles >= 192) return 1;
-    int s = (384 + tiles - 1) / tiles;
-    if (s > nkt / 4) s = nkt / 4;
-    if (s > 16) s = 16;
-    return s < 1 ? 1 : s;
+// Split-K choice by a small cost model (all in microseconds): the grid runs in waves of `capacity`
+// co-resident workgroups (2 per CU); a workgroup spends ~t_tile per 64-deep k-tile; splitting adds the
+// slab write + reduce pass.  Picks the split with the smallest estimated makespan.
+static int pick_splitk(int tiles, int nkt, double out_elems, int bn) {
+    const int capacity = 512;
+    const double t_tile = (bn == 160 ? 1.0 : bn == 128 ? 0.8 : 0.45);
+    int best = 1;
+    double best_t = 1e30;
+    const int smax = nkt / 2 < 16 ? (nkt / 2 < 1 ? 1 : nkt / 2) : 16;
+    for (int s = 1; s <= smax; ++s) {
+        const int kps = (nkt + s - 1) / s;
+        const int se = (nkt + kps - 1) / kps;          // effective splits
+        if (se != s) continue;
+        const double waves = (double)((tiles * s + capacity - 1) / capacity);
+        double t = waves * kps * t_tile + 2.0;
+        if (s > 1) t += 2.5 + 2.0 * s * out_elems * 4.0 / 4.0e6;   // slab write + read at ~4 TB/s, + launch
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    return best;
 }
 
 static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -368,7 +382,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     a.tiles_m = (a.M + 127) / 128;
     a.tiles_n = (a.N + bn - 1) / bn;
     const int nkt = (a.K + 63) / 64;
-    int sk = pick_splitk(a.tiles_m * a.tiles_n, nkt);
+    int sk = pick_splitk(a.tiles_m * a.tiles_n, nkt, (double)a.M * a.N, bn);
     while (sk > 1 && (size_t)sk * a.M * a.N * sizeof(float) > ws_bytes) --sk;
     a.kt_per_split = (nkt + sk - 1) / sk;
     sk = (nkt + a.kt_per_split - 1) / a.kt_per_split;

@@ -12,6 +12,7 @@
 // distinct banks.  The pixel range is split across workgroups (split-K); partial sums are combined
 // with fp32 atomics into a zero-initialised (or accumulating) fp32 gradient buffer.
 #include "common.h"
+#include <stdlib.h>
 
 struct WgradArgs {
     const bf16_t* dy;   // [M][Cout]
@@ -22,6 +23,7 @@ struct WgradArgs {
     int tiles_co, tiles_ci, taps, splits, kt_per_split;
     int use_atomic;
     int ldx;            // dense: row stride of x
+    float* dbias;       // optional [Cout] fp32, pre-zeroed: column sums of dy (bias gradient), or null
 };
 
 constexpr int WG_BT = 160;          // channels per tile side
@@ -98,6 +100,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient rides along in the workgroups that own (ci tile 0, tap 0): they see every dy row once
+    const bool do_bias = p.dbias != nullptr && tile_ci == 0 && tap == 0;
+    float bsum[WG_CH][8];
+#pragma unroll
+    for (int i = 0; i < WG_CH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[i][e] = 0.f;
 
     // transposed-read addressing: 16-lane group g reads pixels kbase + 4g + q (then +16), q = (lane&15)>>2,
     // channels c0 + 4*(lane&3) .. +3; lane i of the group receives channel c0 + i for those 4 pixels.
@@ -108,6 +117,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         __syncthreads();           // previous tile fully consumed
         store_tile();
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < WG_CH; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[i][e] += (float)a_reg[i][e];
+        }
         __syncthreads();
         if (kt + 1 < kt_end) load_tile(kt + 1);
 #pragma unroll
@@ -129,6 +144,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)smem;               // [64 pixel rows][160 channels]
+#pragma unroll
+        for (int i = 0; i < WG_CH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[lp * WG_BT + (lc + 4 * i) * 8 + e] = bsum[i][e];
+        __syncthreads();
+        if (tid < WG_BT && co0 + tid < p.Cout) {
+            float v = 0.f;
+            for (int r = 0; r < WG_BK; ++r) v += red[r * WG_BT + tid];
+            atomicAdd(p.dbias + co0 + tid, v);
         }
     }
 
@@ -199,23 +229,35 @@ static void colsum_geometry(int M, int N, int seg, int* rows_per_block, int* chu
 
 extern "C" {
 
-int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
-                     int stride, int ups, int Ho, int Wo, int accumulate, void* stream) {
+int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
+                     int ksize, int stride, int ups, int Ho, int Wo, int accumulate, void* stream) {
     if (!dy || !x || !dw) return mi355_fail(MI355_ERR_ARG, "wgrad: null pointer");
     if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "wgrad: ksize %d", ksize);
     if ((Cin & 7) || (Cout & 7)) return mi355_fail(MI355_ERR_ARG, "wgrad: channels must be multiples of 8");
     WgradArgs a = {};
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.dw = dw;
     a.M = B * Ho * Wo; a.Cout = Cout; a.Cin = Cin; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
-    a.stride = stride; a.ups = ups; a.ksize = ksize; a.ldx = Cin;
+    a.stride = stride; a.ups = ups; a.ksize = ksize; a.ldx = Cin; a.dbias = dbias;
     a.taps = ksize * ksize;
     a.tiles_co = (Cout + WG_BT - 1) / WG_BT;
     a.tiles_ci = (Cin + WG_BT - 1) / WG_BT;
     const int tiles = a.tiles_co * a.tiles_ci * a.taps;
     const int nkt = (a.M + WG_BK - 1) / WG_BK;
-    int s = (512 + tiles - 1) / tiles;
-    if (s > nkt / 4) s = nkt / 4;
-    if (s < 1) s = 1;
+    // split choice: waves of 512 co-resident workgroups, ~1 us per 64-pixel k-tile, fp32 atomics at ~1.3 TB/s
+    int s = 1;
+    {
+        const double out_bytes = (double)Cout * a.taps * Cin * 4.0;
+        double best_t = 1e30;
+        const int smax = nkt / 2 < 64 ? (nkt / 2 < 1 ? 1 : nkt / 2) : 64;
+        for (int c = 1; c <= smax; ++c) {
+            const int kps = (nkt + c - 1) / c;
+            if ((nkt + kps - 1) / kps != c) continue;
+            const double waves = (double)((tiles * c + 511) / 512);
+            double t = waves * kps * 1.0;
+            if (c > 1) { const double ta = c * out_bytes / 1.3e6; t = (t > ta ? t : ta) + 0.25 * (t < ta ? t : ta); }
+            if (t < best_t) { best_t = t; s = c; }
+        }
+    }
     a.kt_per_split = (nkt + s - 1) / s;
     a.splits = (nkt + a.kt_per_split - 1) / a.kt_per_split;
     a.use_atomic = (a.splits > 1 || accumulate) ? 1 : 0;
@@ -224,6 +266,8 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int
         hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * a.taps * Cin * sizeof(float), st);
         if (e != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed: %s", hipGetErrorString(e));
     }
+    if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st) != hipSuccess)
+        return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed");
     ProfScope prof(FAM_WGRAD, st, 2.0 * a.M * Cout * (double)a.taps * Cin);
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a);
     return mi355_check_launch("wgrad_kernel");

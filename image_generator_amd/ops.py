@@ -85,16 +85,17 @@ def conv2d(x, w, cout, ksize, stride=1, ups=False, dil=False, out_hw=None, bias=
     return out
 
 
-def wgrad(dy, x, cin, cout, ksize=1, stride=1, ups=False, geom=None, out=None, accumulate=False):
-    """fp32 [Cout][k*k][Cin].  Linear: dy [M,Cout], x [M,Cin].  Conv: geom=(B,H,W,Ho,Wo)."""
+def wgrad(dy, x, cin, cout, ksize=1, stride=1, ups=False, geom=None, out=None, accumulate=False, dbias=None):
+    """fp32 [Cout][k*k][Cin].  Linear: dy [M,Cout], x [M,Cin].  Conv: geom=(B,H,W,Ho,Wo).
+    dbias (optional fp32 [Cout]) receives the bias gradient from the same pass."""
     if geom is None:
         B, H, W, Ho, Wo = dy.shape[0], 1, 1, 1, 1
     else:
         B, H, W, Ho, Wo = geom
     if out is None:
         out = torch.empty((cout, ksize * ksize, cin), dtype=F32, device=dy.device)
-    check(lib.mi355_wgrad_bf16(dy.data_ptr(), x.data_ptr(), out.data_ptr(), B, H, W, cin, cout, ksize, stride, int(ups),
-                               Ho, Wo, int(accumulate), _stream()), "wgrad")
+    check(lib.mi355_wgrad_bf16(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _ptr(dbias), B, H, W, cin, cout, ksize, stride,
+                               int(ups), Ho, Wo, int(accumulate), _stream()), "wgrad")
     return out
 
 
@@ -187,23 +188,26 @@ class LinearFn(torch.autograd.Function):
         dx = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = gemm(dy2, pack.w16_t.view(pack.k, pack.n)).view(ctx.xshape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy2)[0]
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2.view(dy.shape)
         dws = [None] * len(ctx.wshapes)
         if any(ctx.wreq):
+            if want_db:
+                db = torch.empty(pack.n, dtype=F32, device=dy2.device)
             if pack.grad_out is not None:
-                wgrad(dy2, x2, pack.k, pack.n, out=pack.grad_out)
+                wgrad(dy2, x2, pack.k, pack.n, out=pack.grad_out, dbias=db)
                 if pack.on_grad_ready is not None:
                     pack.on_grad_ready()
             else:
-                dw = wgrad(dy2, x2, pack.k, pack.n).view(pack.n, pack.k)
+                dw = wgrad(dy2, x2, pack.k, pack.n, dbias=db).view(pack.n, pack.k)
                 r0 = 0
                 for i, shp in enumerate(ctx.wshapes):
                     if ctx.wreq[i]:
                         dws[i] = dw[r0:r0 + shp[0]].view(shp)
                     r0 += shp[0]
+        elif want_db:
+            db = colsum(dy2)[0]
         return (dx, None, db, dres, None, *dws)
 
 
@@ -240,20 +244,25 @@ class ConvFn(torch.autograd.Function):
                 check(lib.mi355_sumpool2x2_bf16(dxv.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "sumpool2x2")
             else:
                 dx = dxv
+        want_db = ctx.flags[0] and ctx.needs_input_grad[2]
+        dbp = None
         if ctx.wreq:
+            if want_db:
+                dbp = torch.empty(pack.cout_pad, dtype=F32, device=dy.device)
             if pack.grad_out is not None:
                 wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo),
-                      out=pack.grad_out)
+                      out=pack.grad_out, dbias=dbp)
                 if pack.on_grad_ready is not None:
                     pack.on_grad_ready()
             else:
-                dwp = wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo))
+                dwp = wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo),
+                            dbias=dbp)
                 dwp = dwp.view(pack.cout_pad, pack.ksize, pack.ksize, pack.cin_pad)
                 # logical OIHW view of the physical [O][kh][kw][I] buffer (channels_last), sliced to the true sizes
                 dw = dwp.permute(0, 3, 1, 2)[:pack.cout, :pack.cin]
         dy2 = dy.view(-1, Co)
-        if ctx.flags[0] and ctx.needs_input_grad[2]:
-            db = colsum(dy2)[0][:pack.cout]
+        if want_db:
+            db = (dbp if dbp is not None else colsum(dy2)[0])[:pack.cout]
         if ctx.flags[1] and ctx.needs_input_grad[3]:
             drb = colsum(dy2, seg=Ho * Wo)
         if ctx.flags[2] and ctx.needs_input_grad[4]:

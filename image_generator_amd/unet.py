@@ -440,6 +440,17 @@ class UNet2DConditionModel(nn.Module):
                 pk.w16 = self._flat16[o0:o0 + pk.n * pk.k].view(pk.n, pk.k)
                 pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
                 self._packs.append(("fused", m, pk, o0))
+        # one job table for every per-step weight transpose: (src, dst, R, C, T, first tile)
+        jobs, first = [], 0
+        for kind, m, pk, o in self._packs:
+            if kind in ("linear", "fused"):
+                R, C, T = pk.n, pk.k, 1
+            else:
+                R, C, T = pk.cout_pad, pk.cin_pad, pk.ksize * pk.ksize
+            jobs.append([pk.w16.data_ptr(), pk.w16_t.data_ptr(), R, C, T, first])
+            first += ((R + 63) // 64) * ((C + 63) // 64) * T
+        self._tjobs = torch.tensor(jobs, dtype=torch.int64, device=dev)
+        self._ttiles = first
         self._layout = (dev, params[0].data_ptr())
         self._sig = None
 
@@ -458,16 +469,12 @@ class UNet2DConditionModel(nn.Module):
         if cast:
             check(lib.mi355_cast_f32_to_bf16(self._flat.data_ptr(), self._flat16.data_ptr(), self._flat.numel(), s), "cast")
         for kind, m, pk, o in self._packs:
-            if kind in ("linear", "fused"):
-                check(lib.mi355_transpose_bf16(pk.w16.data_ptr(), pk.w16_t.data_ptr(), 1, pk.n, pk.k, s), "transpose")
-            else:
+            if kind == "conv" and m.padded:
                 t = pk.ksize * pk.ksize
-                if m.padded:
-                    phys = m.weight.data.permute(0, 2, 3, 1).reshape(pk.cout, t, pk.cin)
-                    pk.w16[:pk.cout, :, :pk.cin] = phys.to(BF16)
-                    pk.bias_pad[:pk.cout] = m.bias.data
-                check(lib.mi355_conv_weight_transpose(pk.w16.data_ptr(), pk.w16_t.data_ptr(), pk.cout_pad, t, pk.cin_pad, s),
-                      "conv_weight_transpose")
+                phys = m.weight.data.permute(0, 2, 3, 1).reshape(pk.cout, t, pk.cin)
+                pk.w16[:pk.cout, :, :pk.cin] = phys.to(BF16)
+                pk.bias_pad[:pk.cout] = m.bias.data
+        check(lib.mi355_transpose_batched(self._tjobs.data_ptr(), self._tjobs.shape[0], self._ttiles, s), "transpose_batched")
         self._sig = self._signature()
 
     def _maybe_refresh(self):

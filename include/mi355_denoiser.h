@@ -63,9 +63,10 @@ int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, 
                       size_t workspace_bytes, void* stream);
 
 /* Weight gradient dw[Cout][k*k][Cin] (fp32) = sum over output pixels of dy[m][co] * im2col(x)[m][tap][ci].
- * Linear layers: ksize=1, H=W=Ho=Wo=1, B = rows.  accumulate=0 overwrites dw, 1 adds to it. */
-int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
-                     int stride, int ups, int Ho, int Wo, int accumulate, void* stream);
+ * Linear layers: ksize=1, H=W=Ho=Wo=1, B = rows.  accumulate=0 overwrites dw, 1 adds to it.
+ * dbias (optional, [Cout] fp32) receives the column sums of dy (bias gradient) from the same pass. */
+int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
+                     int ksize, int stride, int ups, int Ho, int Wo, int accumulate, void* stream);
 
 /* out[s][n] = sum of the rows of segment s (seg rows each) of y[M][N] (bias / broadcast gradients). */
 long long mi355_colsum_scratch_floats(int M, int N, int seg);
@@ -107,6 +108,9 @@ int mi355_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 int mi355_cast_bf16_to_f32(const void* x, float* y, long long n, void* stream);
 int mi355_transpose_bf16(const void* in, void* out, int G, int R, int C, void* stream);    /* [G][R][C]->[G][C][R] */
 int mi355_conv_weight_transpose(const void* w, void* wt, int Co, int taps, int Ci, void* stream);
+/* Many weight transposes in ONE launch.  jobs (device, 6 int64 each): src ptr, dst ptr, R, C, T, first tile;
+ * src [R][T][C] -> dst [C][T reversed][R] (T = 1: plain transpose).  total_tiles = sum of 64x64 tiles x T. */
+int mi355_transpose_batched(const long long* jobs, int njobs, int total_tiles, void* stream);
 int mi355_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int Cs, int Cd, int HW, void* stream);
 int mi355_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int Cs, int Cd, int HW, void* stream);
 int mi355_sumpool2x2_bf16(const void* dy, void* dx, int B, int H, int W, int C, void* stream);

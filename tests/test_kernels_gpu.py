@@ -130,8 +130,10 @@ def test_conv_backward(B, H, W, C, Co, k, stride, ups):
         dx = dxv
     assert rel_l2(dx, xr.grad) < 8e-3, rel_l2(dx, xr.grad)
     Ho, Wo = ref.shape[1], ref.shape[2]
-    dw = ops.wgrad(dy.to(d), x.to(d), C, Co, k, stride, ups, geom=(B, H, W, Ho, Wo)).view(Co, k, k, C)
+    dbf = torch.full((Co,), -3.0, device=d)
+    dw = ops.wgrad(dy.to(d), x.to(d), C, Co, k, stride, ups, geom=(B, H, W, Ho, Wo), dbias=dbf).view(Co, k, k, C)
     assert rel_l2(dw, wr.grad) < 2e-3, rel_l2(dw, wr.grad)
+    close(dbf, dy.float().sum((0, 1, 2)), 1e-3, 1e-2, "conv bias gradient fused into wgrad")
     close(dw, wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), "wgrad conv")
 
 
@@ -147,11 +149,13 @@ def test_linear_backward(M, N, K):
     assert torch.equal(wt.cpu(), w.t().contiguous())
     dx = ops.gemm(dy.to(d), wt)
     assert rel_l2(dx, dy.float() @ w.float()) < 5e-3
-    dw = ops.wgrad(dy.to(d), x.to(d), K, N).view(N, K)
+    dbf = torch.full((N,), 7.0, device=d)          # poisoned: the call must overwrite it
+    dw = ops.wgrad(dy.to(d), x.to(d), K, N, dbias=dbf).view(N, K)
     ref = dy.float().t() @ x.float()
     assert rel_l2(dw, ref) < 1e-3, rel_l2(dw, ref)
     db = ops.colsum(dy.to(d))[0]
     close(db, dy.float().sum(0), 1e-3, 1e-2, "colsum")
+    close(dbf, dy.float().sum(0), 1e-3, 1e-2, "bias gradient fused into wgrad")
     if M % 32 == 0:
         seg = ops.colsum(dy.to(d), seg=M // 32)
         close(seg, dy.float().view(32, M // 32, N).sum(1), 1e-3, 1e-2, "colsum seg")
