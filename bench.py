@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--small", action="store_true", help="plumbing-size model (NOT the headline config)")
+    ap.add_argument("--no-graph", action="store_true", help="run the eager step even on one GPU")
     return ap.parse_args()
 
 
@@ -90,6 +91,10 @@ def main():
     ctx = torch.randn(B, args.ctx_len, cfg.cross_attention_dim, device=dev, generator=g).to(torch.bfloat16)
     ts = torch.randint(0, 1000, (B,), device=dev, generator=g)
 
+    graphed = world == 1 and not args.no_graph
+    if graphed:
+        trainer.capture(lat, noise, ts, ctx)     # one HIP graph for forward + backward + optimizer
+
     def step(i):
         return trainer.train_step(lat, noise, ts, ctx, epoch_float=1.0 + i * 1e-3)
 
@@ -119,6 +124,7 @@ def main():
     fams = ["gemm_conv", "wgrad", "attention", "norm", "elementwise"]
     prof = {}
     if args.prof_steps > 0:
+        trainer._graph = None                      # event timing needs the eager launches
         lib.mi355_prof_enable(1)
         for i in range(args.prof_steps):
             step(args.warmup + args.steps + i)
@@ -151,7 +157,8 @@ def main():
                "config": {"workload": "denoiser train step 256x256 (latent 32x32), SD-v1 UNet 859.5M params, "
                                       "text cross-attention T=77" if not args.small else "small plumbing model",
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                          "optimizer": "fused AdamW + global-norm clip", "final_loss": final_loss},
+                          "optimizer": "fused AdamW + global-norm clip", "final_loss": final_loss,
+                          "hip_graph": bool(graphed)},
                "step_mfma_frac": step_flops / (ms * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12) if not args.small else None,
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

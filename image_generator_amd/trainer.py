@@ -53,18 +53,18 @@ class GradBucketReducer:
     makes the compute stream wait for all communication.
     """
 
-    def __init__(self, unet, group=None, bucket_mb=64, device=None):
-        self.unet = unet
+    def __init__(self, flat_grad, n_big, grad_packs, group=None, bucket_mb=64):
+        """flat_grad: fp32 gradient buffer; [0, n_big) holds the GEMM weights, the rest small parameters;
+        grad_packs: (offset, numel, pack) per layer, `pack.on_grad_ready` is installed here."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.flat_grad = unet.enable_direct_grads()
+        self.flat_grad = flat_grad
         self.device = self.flat_grad.device
         self.use_cuda = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_cuda else None
-        n_big = unet._n_big
         bucket_elems = max(1, int(bucket_mb * (1 << 20) // 4))
         # bucket boundaries over [0, n_big) aligned to weight boundaries, then one tail bucket
-        packs = sorted(unet._grad_packs, key=lambda t: t[0])
+        packs = sorted(grad_packs, key=lambda t: t[0])
         self.buckets = []      # (start, end, [packs])
         cur_start, cur_packs = 0, []
         for o, n, pk in packs:
@@ -75,9 +75,8 @@ class GradBucketReducer:
         if cur_packs or cur_start < n_big:
             self.buckets.append([cur_start, n_big, cur_packs])
         self.tail = (n_big, self.flat_grad.numel())
-        self._pending = []
+        self.active = self.world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1"
         self._counts = []
-        self._handles = []
         self._stage = [torch.empty(e - s, dtype=BF16, device=self.device) for s, e, _ in self.buckets]
         self._tail_stage = torch.empty(self.tail[1] - self.tail[0], dtype=BF16, device=self.device)
         for bi, (s, e, pks) in enumerate(self.buckets):
@@ -87,7 +86,6 @@ class GradBucketReducer:
 
     def reset(self):
         self._counts = [len(pks) for _, _, pks in self.buckets]
-        self._handles = []
 
     def _launch(self, start, end, stage):
         g = self.flat_grad[start:end]
@@ -106,13 +104,13 @@ class GradBucketReducer:
 
     def _ready(self, b):
         self._counts[b] -= 1
-        if self._counts[b] == 0 and self.world > 1:
+        if self._counts[b] == 0 and self.active:
             s, e, _ = self.buckets[b]
             self._launch(s, e, self._stage[b])
 
     def finish(self):
         """Call after backward: flush buckets that never fired, reduce the tail, join the streams."""
-        if self.world > 1:
+        if self.active:
             for b, c in enumerate(self._counts):
                 if c > 0:
                     s, e, _ = self.buckets[b]
@@ -182,7 +180,10 @@ class DenoiserTrainer:
         self.unet = unet
         self.opt = FusedAdamW(unet, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.reducer = GradBucketReducer(unet, group=group, bucket_mb=bucket_mb) if self.world > 1 else None
+        self.reducer = None
+        if self.world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1":
+            self.reducer = GradBucketReducer(unet.enable_direct_grads(), unet._n_big, unet._grad_packs, group=group,
+                                             bucket_mb=bucket_mb)
         dev = self.opt.flat.device
         if alphas_cumprod is None:
             from .schedulers import sd_alphas_cumprod
@@ -205,9 +206,51 @@ class DenoiserTrainer:
 
     def train_step(self, latents, noise, t, ctx, epoch_float=None):
         lr = None if epoch_float is None else cosine_warm_restarts_lr(self.base_lr, epoch_float)
+        if self._graph is not None:
+            return self._replay(latents, noise, t, ctx, lr)
         loss = self.forward_backward(latents, noise, t, ctx)
         self.opt.step(lr=lr, grad_prescale=1.0 / self.world)
         return loss
+
+    # ---- whole-step HIP graph (static shapes): forward, backward and optimizer replayed as one graph,
+    # per-step scalars (lr, bias corrections) are staged into a device buffer before each replay
+    _graph = None
+
+    def capture(self, latents, noise, t, ctx):
+        """Capture one full step for these shapes.  Two un-captured warm-up steps run first with lr = 0
+        (weights unchanged; optimizer moments and step count are reset afterwards)."""
+        if self.world > 1:
+            raise RuntimeError("capture(): the graphed step is single-process; multi-GPU runs the eager step")
+        self._static = tuple(x.clone() for x in (latents, noise, t, ctx))
+        opt = self.opt
+        keep = (opt.lr, opt.wd)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                opt.lr, opt.wd = 0.0, 0.0
+                self.forward_backward(*self._static)
+                opt.step(lr=0.0, grad_prescale=1.0)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        opt.lr, opt.wd = keep
+        opt.m.zero_()
+        opt.v.zero_()
+        opt.t = 0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_loss = self.forward_backward(*self._static)
+            opt.apply()
+        self._graph = g
+
+    def _replay(self, latents, noise, t, ctx, lr):
+        for dst, src in zip(self._static, (latents, noise, t, ctx)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.opt.set_hyper(lr, grad_prescale=1.0)
+        self._graph.replay()
+        return self._static_loss
 
 
 def init_distributed():

@@ -1,0 +1,59 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient reducer of the data-parallel step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Pack:
+    on_grad_ready = None
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from image_generator_amd.trainer import GradBucketReducer
+    sizes = [4096, 1024, 8192, 512, 2048, 16384]          # "GEMM weights"
+    n_big, tail = sum(sizes), 300
+    flat = torch.zeros(n_big + tail)
+    packs, off = [], 0
+    for n in sizes:
+        packs.append((off, n, _Pack()))
+        off += n
+    red = GradBucketReducer(flat, n_big, packs, bucket_mb=0.03)     # ~8k floats per bucket -> several buckets
+    assert len(red.buckets) >= 2
+    for step in range(2):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        local = torch.randn(n_big + tail, generator=g)
+        flat[n_big:] = local[n_big:]
+        # "backward": layers finish in reverse order, each writes its slice then signals
+        for o, n, pk in reversed(packs):
+            flat[o:o + n] = local[o:o + n]
+            pk.on_grad_ready()
+        red.finish()
+        out[(rank, step)] = flat.clone()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    for step in range(2):
+        locs = [torch.randn(4096 + 1024 + 8192 + 512 + 2048 + 16384 + 300, generator=torch.Generator().manual_seed(100 * step + r))
+                for r in range(world)]
+        want = sum(l.to(torch.bfloat16).float() for l in locs)        # bf16 pack, sum, unpack
+        for r in range(world):
+            got = out[(r, step)]
+            assert torch.allclose(got, want, rtol=2e-2, atol=2e-2)
+            assert torch.equal(out[(0, step)], got)                   # every rank holds the same reduced gradient

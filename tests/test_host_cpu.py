@@ -1,0 +1,125 @@
+"""CPU: host-side logic of the product (tokenizer, data-plane indexing, LR schedule, text encoder module,
+state-dict compatibility) and the C-ABI library (loads, exports every declared symbol, argument errors)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_library_exports_every_declared_symbol():
+    from image_generator_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(raw, name), name
+    assert _lib.lib.mi355_abi_version() == 1
+
+
+def test_library_rejects_bad_arguments_without_touching_the_gpu():
+    from image_generator_amd._lib import lib, check, LibraryError
+    rc = lib.mi355_gemm_bf16(None, 8, None, 8, 8, 8, 8, None, 8, 0, None, None, 1, 0, None, 0, 1.0, None, None, 0, 0.0,
+                             None, 0, None)
+    assert rc == -1 and b"null pointer" in lib.mi355_last_error()
+    rc = lib.mi355_conv2d_bf16(1, 1, 4, 4, 8, 1, 8, 5, 1, 0, 0, 4, 4, 1, 0, None, None, 0, None, 1.0, None, 0, None)
+    assert rc == -3 and b"ksize" in lib.mi355_last_error()
+    with pytest.raises(LibraryError):
+        check(lib.mi355_attention_fwd(1, 1, 1, 1, None, 1, 8, 16, 16, 200, 8, 8, 8, 8, 1.0, None), "attention")
+    assert lib.mi355_groupnorm_scratch_floats(2, 64, 320, 32) > 0
+    assert lib.mi355_colsum_scratch_floats(1024, 320, 1024) > 0
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    from image_generator_amd.loss import ContrastiveLoss
+    m = UNet2DConditionModel(DenoiserConfig.small())
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 4, 8, 8), torch.tensor([1]), torch.randn(1, 4, 64))
+    with pytest.raises(RuntimeError):
+        ContrastiveLoss()(torch.randn(4, 8), torch.randn(4, 8))
+
+
+def test_denoiser_state_dict_is_checkpoint_compatible():
+    from oracle.denoiser_ref import DenoiserRef, DenoiserConfig as RC
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    ref, hip = DenoiserRef(RC.small()), UNet2DConditionModel(DenoiserConfig.small())
+    sr, sh = ref.state_dict(), hip.state_dict()
+    assert list(sr.keys()) == list(sh.keys())
+    assert all(sr[k].shape == sh[k].shape for k in sr)
+    hip.load_state_dict(sr)
+    for k in sr:
+        assert torch.equal(hip.state_dict()[k], sr[k])
+    assert "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight" in sh
+    assert "up_blocks.1.upsamplers.0.conv.weight" in sh and "mid_block.resnets.1.time_emb_proj.bias" in sh
+    # conv weights keep the OIHW logical shape with [O][kh][kw][I] memory
+    w = hip.down_blocks[0].resnets[0].conv1.weight
+    assert w.shape[2:] == (3, 3) and w.stride()[1] == 1
+
+
+def test_text_encoder_module_matches_reference_vectors(golden_dir):
+    from image_generator_amd.text_encoder import TextEncoder
+    z = np.load(os.path.join(golden_dir, "text_encoder.npz"))
+    m = TextEncoder(vocab_size=200, embed_dim=32, num_layers=2, n_head=4, projection_dim=24, dropout=0.2)
+    m.load_state_dict({k[4:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd__")})
+    meta = json.load(open(os.path.join(golden_dir, "text_encoder_meta.json")))
+    assert len(TextEncoder().state_dict()) == meta["n_keys"]
+    assert sum(p.numel() for p in TextEncoder().parameters()) == meta["default_param_count"]
+    ids, mask = torch.tensor(z["ids"]), torch.tensor(z["mask"])
+    m.eval()
+    with torch.no_grad():
+        assert torch.allclose(m(ids, mask, return_pooled=False), torch.tensor(z["eval_seq"]), atol=2e-6)
+        assert torch.allclose(m(ids, mask, return_pooled=True), torch.tensor(z["eval_pooled"]), atol=2e-6)
+
+
+def test_tokenizer_ids_bit_exact(golden_dir):
+    from image_generator_amd.tokenizer import load_tokenizer, HashTokenizer
+    d = json.load(open(os.path.join(golden_dir, "tokenizer_cases.json")))
+    tok = load_tokenizer(os.path.join(golden_dir, "tokenizer_tiny.json"))
+    e = tok(d["texts"], padding="max_length", max_length=77, truncation=True, return_tensors="pt")
+    assert e.input_ids.tolist() == d["ids77"] and e.attention_mask.tolist() == d["mask77"]
+    e = tok(d["texts"][:3], padding=True, max_length=128, truncation=True, return_tensors="pt")
+    assert e.input_ids.tolist() == d["ids_longest"] and e.attention_mask.tolist() == d["mask_longest"]
+    assert (tok.pad_token_id, tok.cls_token_id, tok.sep_token_id) == (d["pad"], d["cls"], d["sep"]) == (0, 1, 2)
+    h = HashTokenizer(1000)
+    e = h(["1girl blue_archive shiroko_(blue_archive)", "", "x " * 200], padding="max_length", max_length=77)
+    assert e.input_ids.shape == (3, 77) and e.input_ids[0, 0] == 1 and e.input_ids[1, 1] == 2
+    assert int(e.attention_mask[0].sum()) == 8 and int(e.attention_mask[2].sum()) == 77 and e.input_ids[2, 76] == 2
+    assert e.input_ids[0, 2] == e.input_ids[0, 5]            # the same token hashes to the same id
+    assert h(["a b c", "a"], padding="longest").input_ids.shape == (2, 5)
+
+
+def test_dataplane_indexing_bit_exact(golden_dir):
+    from image_generator_amd import dataplane as dp
+    h = json.load(open(os.path.join(golden_dir, "host_logic.json")))
+    for c in h["sampler"]:
+        assert dp.distributed_sampler_indices(c["n"], c["world"], c["rank"], c["epoch"], 0, c["drop_last"]) == c["idx"]
+    assert dp.lmdb_keys(123456) == (b"image-00123456", b"meta-00123456")
+    assert dp.lmdb_length(20001) == 10000 and dp.next_index_on_decode_failure(9, 10) == 0
+    z = np.load(os.path.join(golden_dir, "collate.npz"))
+    r = dp.skip_broken_collate_fn([{"image": torch.tensor(z["a"]), "text": "a b"}, None, {"image": torch.tensor(z["b"]), "text": "c"}])
+    assert torch.equal(r["image"], torch.tensor(z["r1_images"])) and r["text"] == ["a b", "c"]
+    assert dp.skip_broken_collate_fn([None]) is None
+
+
+def test_lr_schedule_matches_torch(golden_dir):
+    from image_generator_amd.trainer import cosine_warm_restarts_lr
+    h = json.load(open(os.path.join(golden_dir, "host_logic.json")))
+    for e, lr in h["lr"]:
+        assert abs(cosine_warm_restarts_lr(1e-4, e) - lr) <= 1e-12 + 1e-9 * lr
+
+
+def test_ddim_schedule_host_side():
+    from image_generator_amd.schedulers import DDIMScheduler, DDPMScheduler, sd_alphas_cumprod
+    from oracle import ops_ref
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    assert s.timesteps.tolist() == ops_ref.ddim_timesteps(50).tolist()
+    assert torch.equal(sd_alphas_cumprod(), ops_ref.sd_alphas_cumprod())
+    a_t, a_p, g = s.coefficients(1, 7.5)
+    assert a_p == float(s.alphas_cumprod[0]) and g == 7.5
+    assert DDPMScheduler().config.num_train_timesteps == 1000
+    x = torch.randn(2, 4, 4, 4)
+    assert s.scale_model_input(x, 3) is x

@@ -1,0 +1,102 @@
+"""CPU: the oracle restatements (oracle/ops_ref.py) against the golden vectors minted from the
+reference's own modules (tests/golden/make_golden.py), and the denoiser oracle's structural pins."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import ops_ref
+from oracle.denoiser_ref import DenoiserRef, DenoiserConfig, count_params, timestep_embedding
+
+
+def _t(z, k):
+    return torch.tensor(z[k])
+
+
+def test_lora_oracle_matches_reference_vectors(golden_dir):
+    z = np.load(os.path.join(golden_dir, "lora.npz"))
+    for ci in range(2):
+        x = _t(z, f"c{ci}_x").requires_grad_(True)
+        a, b = _t(z, f"c{ci}_a").requires_grad_(True), _t(z, f"c{ci}_bb").requires_grad_(True)
+        bias = _t(z, f"c{ci}_b")
+        y = ops_ref.lora_linear(x, _t(z, f"c{ci}_w"), bias if bias.numel() else None, a, b, float(z[f"c{ci}_alpha"]))
+        y.backward(_t(z, f"c{ci}_go"))
+        assert torch.allclose(y, _t(z, f"c{ci}_y"), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(x.grad, _t(z, f"c{ci}_dx"), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(a.grad, _t(z, f"c{ci}_da"), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(b.grad, _t(z, f"c{ci}_db"), rtol=1e-4, atol=1e-5)
+        fin = z[f"c{ci}_w"].shape[1]
+        assert float(z[f"c{ci}_init_a_absmax"]) <= ops_ref.lora_init_bound(fin) + 1e-7
+    keys = json.load(open(os.path.join(golden_dir, "lora_keys.json")))
+    assert sorted(keys["keys"]) == ["0.lora_A", "0.lora_B", "2.lora_A", "2.lora_B"] and keys["roundtrip_equal"]
+    assert all(v == ["weight"] for v in keys["keys"].values())
+
+
+def test_contrastive_oracle_matches_reference_vectors(golden_dir):
+    z = np.load(os.path.join(golden_dir, "contrastive.npz"))
+    for ci in range(4):
+        t, i = _t(z, f"c{ci}_t").requires_grad_(True), _t(z, f"c{ci}_i").requires_grad_(True)
+        lt = _t(z, f"c{ci}_log_temp").requires_grad_(True)
+        loss = ops_ref.contrastive_loss(t, i, lt)
+        loss.backward()
+        assert torch.allclose(loss, _t(z, f"c{ci}_loss"), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(t.grad, _t(z, f"c{ci}_dt"), rtol=1e-3, atol=1e-6)
+        assert torch.allclose(i.grad, _t(z, f"c{ci}_di"), rtol=1e-3, atol=1e-6)
+        assert torch.allclose(lt.grad, _t(z, f"c{ci}_dlog_temp"), rtol=1e-3, atol=1e-6)
+
+
+def test_text_encoder_oracle_matches_reference_vectors(golden_dir):
+    z = np.load(os.path.join(golden_dir, "text_encoder.npz"))
+    sd = {k[4:]: _t(z, k) for k in z.files if k.startswith("sd__")}
+    ids, mask = _t(z, "ids"), _t(z, "mask")
+    for pooled, key in ((False, "seq"), (True, "pooled")):
+        ev = ops_ref.text_encoder_forward(sd, ids, mask, 4, pooled, zero_padded_rows=True)
+        tr = ops_ref.text_encoder_forward(sd, ids, mask, 4, pooled, zero_padded_rows=False)
+        assert torch.allclose(ev, _t(z, "eval_" + key), rtol=1e-5, atol=2e-6)
+        assert torch.allclose(tr, _t(z, "train_" + key), rtol=1e-5, atol=2e-6)
+    # the two modes differ on padded rows only
+    pad = ~mask.bool()
+    d = (_t(z, "eval_seq") - _t(z, "train_seq")).abs()
+    assert float(d[~pad].max()) < 1e-5 and float(d[pad].max()) > 1e-3
+
+
+def test_collate_oracle(golden_dir):
+    z = np.load(os.path.join(golden_dir, "collate.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "collate.json")))
+    a, b = {"image": _t(z, "a"), "text": "a b"}, {"image": _t(z, "b"), "text": "c"}
+    r = ops_ref.skip_broken_collate([a, None, b])
+    assert sorted(r.keys()) == meta["r1_keys"] and r["text"] == meta["r1_texts"]
+    assert torch.equal(r["image"], _t(z, "r1_images"))
+    assert ops_ref.skip_broken_collate([None, None]) is None
+    assert ops_ref.skip_broken_collate([a, {"image": torch.full((3, 4, 4), float("nan")), "text": "d"}]) is None
+
+
+def test_host_logic_oracle(golden_dir):
+    h = json.load(open(os.path.join(golden_dir, "host_logic.json")))
+    for c in h["sampler"]:
+        assert ops_ref.distributed_sampler_indices(c["n"], c["world"], c["rank"], c["epoch"], 0, c["drop_last"]) == c["idx"]
+    for e, lr in h["lr"]:
+        assert abs(ops_ref.cosine_warm_restarts_lr(1e-4, e) - lr) <= 1e-12 + 1e-9 * lr
+    assert ops_ref.lmdb_keys(7) == (b"image-00000007", b"meta-00000007") and ops_ref.lmdb_length(11) == 5
+
+
+def test_denoiser_oracle_structure():
+    assert count_params(DenoiserRef(DenoiserConfig.sd_v1())) == 859_520_964      # SD-v1 UNet parameter count
+    e = timestep_embedding(torch.tensor([0, 10]), 320)
+    assert torch.allclose(e[0, :160], torch.ones(160)) and torch.allclose(e[0, 160:], torch.zeros(160))
+    m = DenoiserRef(DenoiserConfig.small())
+    x, t, c = torch.randn(2, 4, 8, 8), torch.tensor([1, 999]), torch.randn(2, 5, 64)
+    y = m(x, t, c).sample
+    assert y.shape == x.shape
+    # no attention mask: permuting the context tokens leaves the output unchanged
+    y2 = m(x, t, c[:, torch.randperm(5)]).sample
+    assert torch.allclose(y, y2, atol=1e-5)
+    # DDIM/ DDPM identities
+    acp = ops_ref.sd_alphas_cumprod()
+    assert abs(float(acp[0]) - (1 - 0.00085)) < 1e-6 and float(acp[-1]) < 0.01
+    assert list(ops_ref.ddim_timesteps(50)[:3]) == [981, 961, 941] and ops_ref.ddim_timesteps(50)[-1] == 1
+    x0, eps = torch.randn(1, 4, 4, 4), torch.randn(1, 4, 4, 4)
+    xt = ops_ref.ddpm_add_noise(x0, eps, torch.tensor([481]), acp)
+    prev = ops_ref.ddim_step(eps, 481, xt, acp, 50)             # with the true noise DDIM lands on the t-20 marginal
+    assert torch.allclose(prev, ops_ref.ddpm_add_noise(x0, eps, torch.tensor([461]), acp), atol=1e-5)
