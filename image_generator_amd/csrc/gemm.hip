@@ -51,6 +51,87 @@ struct GemmArgs {
 
 enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2 };
 
+// Shared tail of both GEMM kernels: split-K slab store, or the LDS-staged vectorised epilogue.
+template <int BN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], char* smem, int m0, int n0,
+                                              int split, int wm0, int wn0, int wave, int tid, int fr, int fq) {
+    constexpr int EP_LD = BN + 4;
+    // ---- split-K: raw fp32 partial slab, the reduce kernel applies the epilogue
+    if (p.splitk > 1) {
+        float* dst = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm0 + i * 16 + fq * 4 + r;
+                    const int n = n0 + wn0 + j * 16 + fr;
+                    if (m < p.M && n < p.N) dst[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+
+    // ---- epilogue through LDS, 64 rows at a time
+    float* ep = (float*)smem;
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if ((wave >> 1) == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ep[(i * 16 + fq * 4 + r) * EP_LD + wn0 + j * 16 + fr] = acc[i][j][r];
+        }
+        __syncthreads();
+        constexpr int NC = BN / 8;
+        for (int idx = tid; idx < 64 * NC; idx += 256) {
+            const int row = idx / NC, c8 = idx - row * NC;
+            const int m = m0 + h * 64 + row, n = n0 + c8 * 8;
+            if (m >= p.M || n >= p.N) continue;
+            float v[8];
+            const f32x4 v0 = *(const f32x4*)(ep + row * EP_LD + c8 * 8);
+            const f32x4 v1 = *(const f32x4*)(ep + row * EP_LD + c8 * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] * p.alpha; v[4 + e] = v1[e] * p.alpha; }
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+            }
+            if (p.rowbias) {
+                const float* rb = p.rowbias + (size_t)(m / p.rowbias_div) * p.ld_rowbias + n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rb[e];
+            }
+            if (p.lora_t) {
+                const float* t = p.lora_t + (size_t)m * p.lora_r;
+                for (int r = 0; r < p.lora_r; ++r) {
+                    const float tv = t[r] * p.lora_alpha;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += tv * p.lora_b[(size_t)(n + e) * p.lora_r + r];
+                }
+            }
+            if (p.residual) {
+                const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            if (p.out_fp32) {
+                float* o = (float*)p.out + (size_t)m * p.ldo + n;
+                *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+                *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+                *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = ov;
+            }
+        }
+    }
+}
+
 template <int BN, int AMODE>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     constexpr int BM = 128, BK = 64;
@@ -58,7 +139,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int EP_LD = BN + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -208,80 +288,157 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         cur ^= 1;
     }
 
-    // ---- split-K: raw fp32 partial slab, the reduce kernel applies the epilogue
-    if (p.splitk > 1) {
-        float* dst = p.partial + (size_t)split * p.M * p.N;
+    gemm_epilogue<BN, TM, TN>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant: both operand tiles are written into LDS by `buffer_load ... lds` (no VGPR staging,
+// no ds_write).  One wave instruction fills a 1 KiB piece = 8 tile rows x 128 B in lane order, so the
+// XOR swizzle is applied on the SOURCE side: lane l of a piece fetches k-chunk (l&7)^(l>>3) of row l>>3.
+// Rows outside the problem and padding taps of the implicit im2col get an out-of-range buffer offset:
+// the hardware bounds check returns zeros, which is exactly the zero padding the convolution needs.
+// Pipeline: two LDS stages, ONE barrier per k-tile; the loads of tile t+1 are issued right after the
+// barrier and stay in flight under the MFMAs of tile t.
+// Requirements (checked by the launcher): K % 64 == 0, conv C % 64 == 0, operand sizes < 2 GiB.
+// ---------------------------------------------------------------------------------------------
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr int OOB_OFF = (int)0x80000000;
+
+template <int BN, int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the body uses device-only buffer-resource builtins
+    constexpr int BM = 128, BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int A_P = BM / 32, B_P = BN / 32;          // 1 KiB pieces per wave
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+    const int nwg = gridDim.x;
+    int lid = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = lid % p.tiles_n; lid /= p.tiles_n;
+    const int tile_m = lid % p.tiles_m;
+    const int split = lid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nkt_total = p.K / BK;
+    const int kt_begin = split * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split;
+    if (kt_end > nkt_total) kt_end = nkt_total;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw, 0, b_bytes, 0x00020000);
+
+    const int sr = lane >> 3;               // row inside the 8-row piece
+    const int kc = (lane & 7) ^ sr;         // k-chunk fetched by this lane (source-side swizzle)
+    int a_voff[A_P];                         // dense: byte offset of (row, kc); conv: pixel index of (b,0,0) or -1
+    int a_iy0[A_P], a_ix0[A_P];
+    const int pad = p.g.ksize >> 1;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < A_P; ++j) {
+        const int m = m0 + (wave + 4 * j) * 8 + sr;
+        const bool ok = m < p.M;
+        if constexpr (AMODE == AMODE_DENSE) {
+            a_voff[j] = ok ? (m * p.lda + kc * 8) * 2 : OOB_OFF;
+            a_iy0[j] = a_ix0[j] = 0;
+        } else {
+            const int mm = ok ? m : 0;
+            const int ox = mm % p.g.Wo;
+            const int t = mm / p.g.Wo;
+            const int oy = t % p.g.Ho;
+            const int b = t / p.g.Ho;
+            a_voff[j] = ok ? b * p.g.H * p.g.W : -1;
+            a_iy0[j] = oy * p.g.stride - pad;
+            a_ix0[j] = ox * p.g.stride - pad;
+        }
+    }
+    int b_voff[B_P];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm0 + i * 16 + fq * 4 + r;
-                    const int n = n0 + wn0 + j * 16 + fr;
-                    if (m < p.M && n < p.N) dst[(size_t)m * p.N + n] = acc[i][j][r];
-                }
-        return;
+    for (int j = 0; j < B_P; ++j) {
+        const int n = n0 + (wave + 4 * j) * 8 + sr;
+        b_voff[j] = n < p.N ? (n * p.ldb + kc * 8) * 2 : OOB_OFF;
     }
 
-    // ---- epilogue through LDS, 64 rows at a time
-    float* ep = (float*)smem;
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-        if ((wave >> 1) == h) {
+    auto issue = [&](int kt, int stage) {
+        char* As = smem + stage * STAGE;
+        char* Bs = As + BM * 128;
+        if constexpr (AMODE == AMODE_DENSE) {
+            const int soff = kt * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < A_P; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + 4 * j) * 1024), 16, a_voff[j], soff, 0, 0);
+        } else {
+            const int kk = kt * BK;
+            const int tap = kk / p.g.C;
+            const int soff = (kk - tap * p.g.C) * 2;
+            int ky = 0, kx = 0;
+            if (p.g.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
+#pragma unroll
+            for (int j = 0; j < A_P; ++j) {
+                int sy = a_iy0[j] + ky, sx = a_ix0[j] + kx;
+                bool ok = a_voff[j] >= 0 && sy >= 0 && sx >= 0;
+                if (p.g.dil) {
+                    ok = ok && !((sy | sx) & 1);
+                    sy >>= 1; sx >>= 1;
+                } else if (p.g.ups) {
+                    sy >>= 1; sx >>= 1;
+                }
+                ok = ok && sy < p.g.H && sx < p.g.W;
+                const int voff = ok ? ((a_voff[j] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + 4 * j) * 1024), 16, voff, soff, 0, 0);
+            }
+        }
+        const int soffb = kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < B_P; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(Bs + (wave + 4 * j) * 1024), 16, b_voff[j], soffb, 0, 0);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    if (kt_begin < kt_end) issue(kt_begin, 0);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed
+        __builtin_amdgcn_s_barrier();                         // everyone's have; everyone left tile kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);          // in flight under the MFMAs below
+        const char* As = smem + cur * STAGE;
+        const char* Bs = As + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+            const int ch = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm0 + i * 16 + fr;
+                af[i] = *(const bf16x8*)(As + r * 128 + ((ch ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn0 + j * 16 + fr;
+                bfr[j] = *(const bf16x8*)(Bs + r * 128 + ((ch ^ (r & 7)) << 4));
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        ep[(i * 16 + fq * 4 + r) * EP_LD + wn0 + j * 16 + fr] = acc[i][j][r];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-        constexpr int NC = BN / 8;
-        for (int idx = tid; idx < 64 * NC; idx += 256) {
-            const int row = idx / NC, c8 = idx - row * NC;
-            const int m = m0 + h * 64 + row, n = n0 + c8 * 8;
-            if (m >= p.M || n >= p.N) continue;
-            float v[8];
-            const f32x4 v0 = *(const f32x4*)(ep + row * EP_LD + c8 * 8);
-            const f32x4 v1 = *(const f32x4*)(ep + row * EP_LD + c8 * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = v0[e] * p.alpha; v[4 + e] = v1[e] * p.alpha; }
-            if (p.bias) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
-            }
-            if (p.rowbias) {
-                const float* rb = p.rowbias + (size_t)(m / p.rowbias_div) * p.ld_rowbias + n;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rb[e];
-            }
-            if (p.lora_t) {
-                const float* t = p.lora_t + (size_t)m * p.lora_r;
-                for (int r = 0; r < p.lora_r; ++r) {
-                    const float tv = t[r] * p.lora_alpha;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += tv * p.lora_b[(size_t)(n + e) * p.lora_r + r];
-                }
-            }
-            if (p.residual) {
-                const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-            }
-            if (p.out_fp32) {
-                float* o = (float*)p.out + (size_t)m * p.ldo + n;
-                *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
-                *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
-                bf16x8 ov;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-                *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = ov;
-            }
-        }
+        cur ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_epilogue<BN, TM, TN>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+#endif
 }
 
 // Sums the split-K slabs and applies the same epilogue as the fused path.
@@ -350,6 +507,19 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
 // Split-K choice by a small cost model (all in microseconds): the grid runs in waves of `capacity`
 // co-resident workgroups (2 per CU); a workgroup spends ~t_tile per 64-deep k-tile; splitting adds the
 // slab write + reduce pass.  Picks the split with the smallest estimated makespan.
+template <int BN, int AMODE>
+static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
+    constexpr int smem = 2 * (128 + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    const int grid = a.tiles_m * a.tiles_n * a.splitk;
+    hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE>), dim3(grid), dim3(256), smem, s, a, a_bytes, b_bytes);
+    return mi355_check_launch("gemm_dma_kernel");
+}
+
 static int pick_splitk(int tiles, int nkt, double out_elems, int bn) {
     const int capacity = 512;
     const double t_tile = (bn == 160 ? 1.0 : bn == 128 ? 0.8 : 0.45);
@@ -390,6 +560,22 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     a.partial = (float*)ws;
     ProfScope prof(FAM_GEMM, s, 2.0 * a.M * a.N * a.K);
     int rc;
+    // LDS-DMA kernel when the shape allows it (every large layer of the denoiser does)
+    static const bool force_v1 = getenv("MI355_GEMM_V1") != nullptr;
+    const double a_sz = amode == AMODE_DENSE ? ((double)(a.M - 1) * a.lda + a.K) * 2.0
+                                             : (double)a.g.B * a.g.H * a.g.W * a.g.C * 2.0;
+    const double b_sz = ((double)(a.N - 1) * a.ldb + a.K) * 2.0;
+    const bool dma_ok = !force_v1 && a.K % 64 == 0 && amode != AMODE_CONV_GENERIC && a_sz < 2.0e9 && b_sz < 2.0e9 &&
+                        (double)a.M * (amode == AMODE_DENSE ? a.lda : 1) < 1.0e9;
+    if (dma_ok) {
+        const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
+#define DISPATCH_DMA(BN) (amode == AMODE_DENSE ? launch_gemm_dma<BN, AMODE_DENSE>(a, ab, bb, s) \
+                                               : launch_gemm_dma<BN, AMODE_CONV_FAST>(a, ab, bb, s))
+        if (bn == 160) rc = DISPATCH_DMA(160);
+        else if (bn == 64) rc = DISPATCH_DMA(64);
+        else rc = DISPATCH_DMA(128);
+#undef DISPATCH_DMA
+    } else {
 #define DISPATCH(BN)                                                                       \
     (amode == AMODE_DENSE ? launch_gemm<BN, AMODE_DENSE>(a, s)                             \
      : amode == AMODE_CONV_FAST ? launch_gemm<BN, AMODE_CONV_FAST>(a, s)                   \
@@ -398,6 +584,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     else if (bn == 64) rc = DISPATCH(64);
     else rc = DISPATCH(128);
 #undef DISPATCH
+    }
     if (rc) return rc;
     if (sk > 1) {
         const size_t total = (size_t)a.M * (a.N / 8);
