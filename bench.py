@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--ctx-len", type=int, default=77)
     ap.add_argument("--prof-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--small", action="store_true", help="plumbing-size model (NOT the headline config)")
     ap.add_argument("--no-graph", action="store_true", help="run the eager step even on one GPU")
     return ap.parse_args()
@@ -91,7 +91,7 @@ def main():
     ctx = torch.randn(B, args.ctx_len, cfg.cross_attention_dim, device=dev, generator=g).to(torch.bfloat16)
     ts = torch.randint(0, 1000, (B,), device=dev, generator=g)
 
-    graphed = world == 1 and not args.no_graph
+    graphed = world == 1 and not args.no_graph and trainer.reducer is None
     if graphed:
         trainer.capture(lat, noise, ts, ctx)     # one HIP graph for forward + backward + optimizer
 
@@ -164,7 +164,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -260,13 +260,15 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
     }
     a.kt_per_split = (nkt + s - 1) / s;
     a.splits = (nkt + a.kt_per_split - 1) / a.kt_per_split;
-    a.use_atomic = (a.splits > 1 || accumulate) ? 1 : 0;
+    // accumulate: 0 = overwrite (zero first when split), 1 = add to existing values,
+    //             2 = dw and dbias were zeroed by the caller (plain stores when unsplit, no memsets here)
+    a.use_atomic = (a.splits > 1 || accumulate == 1) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (a.splits > 1 && !accumulate) {
+    if (a.splits > 1 && accumulate == 0) {
         hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * a.taps * Cin * sizeof(float), st);
         if (e != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed: %s", hipGetErrorString(e));
     }
-    if (dbias && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st) != hipSuccess)
+    if (dbias && accumulate == 0 && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st) != hipSuccess)
         return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed");
     ProfScope prof(FAM_WGRAD, st, 2.0 * a.M * Cout * (double)a.taps * Cin);
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a);

@@ -151,12 +151,13 @@ class WeightPack:
     w16_t : data-gradient operand: [K][N] for linear layers, [Cin][k][k][Cout] tap-flipped for convs.
     """
     __slots__ = ("w16", "w16_t", "n", "k", "ksize", "cin", "cout", "cin_pad", "cout_pad", "bias_pad", "grad_out",
-                 "on_grad_ready")
+                 "bias_grad_out", "on_grad_ready")
 
     def __init__(self):
         self.w16 = self.w16_t = None
         self.bias_pad = None      # fp32 bias padded to cout_pad (convolutions whose Cout is not a multiple of 8)
         self.grad_out = None      # optional fp32 [N][K] view the weight gradient is written into directly
+        self.bias_grad_out = None  # optional fp32 [N] view for the bias gradient (both views are pre-zeroed by the owner)
         self.on_grad_ready = None
 
 
@@ -193,13 +194,17 @@ class LinearFn(torch.autograd.Function):
             dres = dy2.view(dy.shape)
         dws = [None] * len(ctx.wshapes)
         if any(ctx.wreq):
-            if want_db:
-                db = torch.empty(pack.n, dtype=F32, device=dy2.device)
             if pack.grad_out is not None:
-                wgrad(dy2, x2, pack.k, pack.n, out=pack.grad_out, dbias=db)
+                # direct mode: the owner zeroed the flat gradient buffer; gradients are written in place
+                if want_db and pack.bias_grad_out is None:
+                    db = torch.zeros(pack.n, dtype=F32, device=dy2.device)
+                wgrad(dy2, x2, pack.k, pack.n, out=pack.grad_out, accumulate=2,
+                      dbias=(pack.bias_grad_out if pack.bias_grad_out is not None else db) if want_db else None)
                 if pack.on_grad_ready is not None:
                     pack.on_grad_ready()
             else:
+                if want_db:
+                    db = torch.empty(pack.n, dtype=F32, device=dy2.device)
                 dw = wgrad(dy2, x2, pack.k, pack.n, dbias=db).view(pack.n, pack.k)
                 r0 = 0
                 for i, shp in enumerate(ctx.wshapes):
@@ -246,22 +251,26 @@ class ConvFn(torch.autograd.Function):
                 dx = dxv
         want_db = ctx.flags[0] and ctx.needs_input_grad[2]
         dbp = None
+        direct_b = False
         if ctx.wreq:
-            if want_db:
-                dbp = torch.empty(pack.cout_pad, dtype=F32, device=dy.device)
+            geom = (B, H, W, Ho, Wo)
             if pack.grad_out is not None:
-                wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo),
-                      out=pack.grad_out, dbias=dbp)
+                direct_b = want_db and pack.bias_grad_out is not None
+                if want_db and not direct_b:
+                    dbp = torch.zeros(pack.cout_pad, dtype=F32, device=dy.device)
+                wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=geom, out=pack.grad_out,
+                      accumulate=2, dbias=(pack.bias_grad_out if direct_b else dbp) if want_db else None)
                 if pack.on_grad_ready is not None:
                     pack.on_grad_ready()
             else:
-                dwp = wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=(B, H, W, Ho, Wo),
-                            dbias=dbp)
+                if want_db:
+                    dbp = torch.empty(pack.cout_pad, dtype=F32, device=dy.device)
+                dwp = wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=geom, dbias=dbp)
                 dwp = dwp.view(pack.cout_pad, pack.ksize, pack.ksize, pack.cin_pad)
                 # logical OIHW view of the physical [O][kh][kw][I] buffer (channels_last), sliced to the true sizes
                 dw = dwp.permute(0, 3, 1, 2)[:pack.cout, :pack.cin]
         dy2 = dy.view(-1, Co)
-        if want_db:
+        if want_db and not direct_b:
             db = (dbp if dbp is not None else colsum(dy2)[0])[:pack.cout]
         if ctx.flags[1] and ctx.needs_input_grad[3]:
             drb = colsum(dy2, seg=Ho * Wo)
@@ -272,7 +281,8 @@ class ConvFn(torch.autograd.Function):
 
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu):
+    def forward(ctx, x, gamma, beta, groups, eps, silu, gdst=None):
+        """gdst: optional (dgamma, dbeta) fp32 views the parameter gradients are written into directly."""
         B, H, W, C = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((B, groups, 2), dtype=F32, device=x.device)
@@ -280,7 +290,7 @@ class GroupNormFn(torch.autograd.Function):
         check(lib.mi355_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                       scratch.data_ptr(), B, H * W, C, groups, eps, int(silu), _stream()), "groupnorm_fwd")
         ctx.save_for_backward(x, stats, gamma, beta)
-        ctx.groups, ctx.silu = groups, silu
+        ctx.groups, ctx.silu, ctx.gdst = groups, silu, gdst
         return y
 
     @staticmethod
@@ -290,18 +300,21 @@ class GroupNormFn(torch.autograd.Function):
         B, H, W, C = x.shape
         G = ctx.groups
         dx = torch.empty_like(x)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(beta)
+        direct = ctx.gdst is not None
+        dg, db = ctx.gdst if direct else (torch.empty_like(gamma), torch.empty_like(beta))
         scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, G)), dtype=F32, device=x.device)
         check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                       dx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), B, H * W, C, G,
                                       int(ctx.silu), _stream()), "groupnorm_bwd")
-        return dx, dg, db, None, None, None
+        if direct:
+            return dx, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, gdst=None):
+        """gdst: optional fp32 [2][C] view (dgamma row, dbeta row) written directly."""
         C = x.shape[-1]
         M = x.numel() // C
         y = torch.empty_like(x)
@@ -309,6 +322,7 @@ class LayerNormFn(torch.autograd.Function):
         check(lib.mi355_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                       M, C, eps, _stream()), "layernorm_fwd")
         ctx.save_for_backward(x, stats, gamma)
+        ctx.gdst = gdst
         return y
 
     @staticmethod
@@ -318,11 +332,14 @@ class LayerNormFn(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
-        dgb = torch.empty((2, C), dtype=F32, device=x.device)
+        direct = ctx.gdst is not None
+        dgb = ctx.gdst if direct else torch.empty((2, C), dtype=F32, device=x.device)
         scratch = torch.empty(int(lib.mi355_layernorm_bwd_scratch_floats(M, C)), dtype=F32, device=x.device)
         check(lib.mi355_layernorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
                                       dgb.data_ptr(), scratch.data_ptr(), M, C, _stream()), "layernorm_bwd")
-        return dx, dgb[0], dgb[1], None
+        if direct:
+            return dx, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None
 
 
 class AttentionFn(torch.autograd.Function):

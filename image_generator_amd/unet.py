@@ -114,9 +114,10 @@ class HipGroupNorm(nn.Module):
         self.num_groups, self.eps = groups, eps
         self.weight = nn.Parameter(torch.ones(channels))
         self.bias = nn.Parameter(torch.zeros(channels))
+        self.grad_dst = None        # (dgamma, dbeta) views of the flat gradient buffer in direct-gradient mode
 
     def forward(self, x, silu):
-        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst)
 
 
 class HipLayerNorm(nn.Module):
@@ -125,9 +126,10 @@ class HipLayerNorm(nn.Module):
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(dim))
         self.bias = nn.Parameter(torch.zeros(dim))
+        self.grad_dst = None        # [2][C] view (dgamma | dbeta) of the flat gradient buffer in direct-gradient mode
 
     def forward(self, x):
-        return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        return LayerNormFn.apply(x, self.weight, self.bias, self.eps, self.grad_dst)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -517,15 +519,23 @@ class UNet2DConditionModel(nn.Module):
             pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
             if kind == "fused" or id(m) not in fused_members:
                 self._grad_packs.append((o, pk.n * pk.k, pk))
+            if kind != "fused" and m.bias is not None:
+                ob = self._offs[id(m.bias)]
+                pk.bias_grad_out = g[ob:ob + m.bias.numel()]
+        for m in self.modules():
+            if isinstance(m, HipGroupNorm):
+                ow, ob, c = self._offs[id(m.weight)], self._offs[id(m.bias)], m.weight.numel()
+                m.grad_dst = (g[ow:ow + c], g[ob:ob + c])
+            elif isinstance(m, HipLayerNorm):
+                ow, ob, c = self._offs[id(m.weight)], self._offs[id(m.bias)], m.weight.numel()
+                m.grad_dst = g[ow:ow + 2 * c].view(2, c) if ob == ow + c else None
         return g
 
     def zero_small_grads(self):
+        """Direct-gradient mode: ONE memset of the flat gradient buffer per step.  Split weight-gradient
+        tiles and the fused bias sums accumulate into it with atomics; everything else is stored once."""
         if self._flat_grad is not None:
-            self._flat_grad[self._n_big:].zero_()
-            for kind, m, pk, o in self._packs:
-                if kind == "conv" and m.padded:
-                    n = m.weight.numel()
-                    self._flat_grad[o:o + n].zero_()
+            check(lib.mi355_zero_f32(self._flat_grad.data_ptr(), self._flat_grad.numel(), _stream()), "zero")
 
     # -------------------------------------------------------------------------------------------
     def forward(self, sample, timestep, encoder_hidden_states=None):

@@ -63,7 +63,8 @@ int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, 
                       size_t workspace_bytes, void* stream);
 
 /* Weight gradient dw[Cout][k*k][Cin] (fp32) = sum over output pixels of dy[m][co] * im2col(x)[m][tap][ci].
- * Linear layers: ksize=1, H=W=Ho=Wo=1, B = rows.  accumulate=0 overwrites dw, 1 adds to it.
+ * Linear layers: ksize=1, H=W=Ho=Wo=1, B = rows.  accumulate: 0 overwrites dw/dbias, 1 adds to them,
+ * 2 = the caller zeroed dw/dbias beforehand (no memset nodes are issued; unsplit tiles use plain stores).
  * dbias (optional, [Cout] fp32) receives the column sums of dy (bias gradient) from the same pass. */
 int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
                      int ksize, int stride, int ups, int Ho, int Wo, int accumulate, void* stream);
