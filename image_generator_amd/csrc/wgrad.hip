@@ -179,6 +179,163 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant of the weight-gradient kernel.  Tiles of 32 pixels x 160 channels per operand are
+// written to LDS by `buffer_load ... lds` in a linear [pixel][176-channel] image (the 16 spare channels
+// per row are fetched out of range = zeros; they give the 352-byte row stride the transposing reads
+// need).  Two LDS stages of 22.5 KB, one barrier per k-tile, next tile's DMA in flight under the MFMAs.
+// Out-of-range pixels / padding taps / channels beyond the tensor use an out-of-range buffer offset.
+// ---------------------------------------------------------------------------------------------
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr int WD_BK = 32;                       // pixels per k-tile
+constexpr int WD_CHUNKS = 22;                   // 16-byte chunks per LDS row (20 real + 2 zero)
+constexpr int WD_TILE = WD_BK * WG_LD;          // bytes per operand tile (11 KiB pieces)
+constexpr int WD_PIECES = WD_BK * WD_CHUNKS / 64;   // 11 per operand
+constexpr int OOB_OFF = (int)0x80000000;
+
+__device__ __forceinline__ int fast_div(int n, int d, float rd) {
+    int q = (int)((float)n * rd);
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p, unsigned dy_bytes, unsigned x_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) char smem[4 * WD_TILE];     // [stage][A | B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 80, wn0 = (wave & 1) * 80;
+
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid % p.splits; lid /= p.splits;
+    const int tile_ci = lid % p.tiles_ci; lid /= p.tiles_ci;
+    const int tile_co = lid % p.tiles_co;
+    const int tap = lid / p.tiles_co;
+    const int co0 = tile_co * WG_BT, ci0 = tile_ci * WG_BT;
+    int ky = 0, kx = 0;
+    if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
+    const int pad = p.ksize >> 1;
+    const bool dense = p.ksize == 1 && p.stride == 1 && !p.ups;
+    const float rWo = 1.0f / (float)p.Wo, rHo = 1.0f / (float)p.Ho;
+
+    const int nkt_total = (p.M + WD_BK - 1) / WD_BK;
+    const int kt_begin = split * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split;
+    if (kt_end > nkt_total) kt_end = nkt_total;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+
+    // this wave's pieces: idx = wave + 4j (< 22); idx < 11 -> dy tile, else x tile
+    int prow[6], pch[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int idx = wave + 4 * j;
+        const int q = (idx % WD_PIECES) * 64 + lane;
+        prow[j] = q / WD_CHUNKS;
+        pch[j] = q - prow[j] * WD_CHUNKS;
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char* As = smem + stage * 2 * WD_TILE;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int idx = wave + 4 * j;
+            if (idx >= 2 * WD_PIECES) continue;
+            const int m = kt * WD_BK + prow[j];
+            const int ch = pch[j] * 8;
+            int voff = OOB_OFF;
+            if (idx < WD_PIECES) {
+                if (m < p.M && pch[j] < 20 && co0 + ch < p.Cout) voff = (m * p.Cout + co0 + ch) * 2;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + idx * 1024), 16, voff, 0, 0, 0);
+            } else {
+                if (m < p.M && pch[j] < 20 && ci0 + ch < p.Cin) {
+                    if (dense) {
+                        voff = (m * p.ldx + ci0 + ch) * 2;
+                    } else {
+                        const int t = fast_div(m, p.Wo, rWo);
+                        const int ox = m - t * p.Wo;
+                        const int b = fast_div(t, p.Ho, rHo);
+                        const int oy = t - b * p.Ho;
+                        int sy = oy * p.stride - pad + ky, sx = ox * p.stride - pad + kx;
+                        bool ok = sy >= 0 && sx >= 0;
+                        if (p.ups) { sy >>= 1; sx >>= 1; }
+                        ok = ok && sy < p.H && sx < p.W;
+                        if (ok) voff = (((b * p.H + sy) * p.W + sx) * p.Cin + ci0 + ch) * 2;
+                    }
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(As + WD_TILE + (idx - WD_PIECES) * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.dbias != nullptr && tile_ci == 0 && tap == 0;
+    float bsum = 0.f;
+
+    const int g = lane >> 4, li = lane & 15;
+    const int tr_off = (4 * g + (li >> 2)) * WG_LD + (li & 3) * 8;
+
+    if (kt_begin < kt_end) issue(kt_begin, 0);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
+        const char* As = smem + cur * 2 * WD_TILE;
+        const char* Bs = As + WD_TILE;
+        bf16x8 af[5], bfr[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const char* pa = As + tr_off + (wm0 + i * 16) * 2;
+            af[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa + 16 * WG_LD));
+            af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const char* pb = Bs + tr_off + (wn0 + i * 16) * 2;
+            const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pb));
+            const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pb + 16 * WG_LD));
+            bfr[i] = bf16x8{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (do_bias && tid < WG_BT) {
+            const bf16_t* col = (const bf16_t*)As + tid;
+#pragma unroll 8
+            for (int r = 0; r < WD_BK; ++r) bsum += (float)col[r * (WG_LD / 2)];
+        }
+        cur ^= 1;
+    }
+    if (do_bias && tid < WG_BT && co0 + tid < p.Cout) atomicAdd(p.dbias + co0 + tid, bsum);
+
+    const int ktot = p.taps * p.Cin;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm0 + i * 16 + g * 4 + r;
+                const int ci = ci0 + wn0 + j * 16 + li;
+                if (co < p.Cout && ci < p.Cin) {
+                    float* dst = p.dw + (size_t)co * ktot + (size_t)tap * p.Cin + ci;
+                    if (p.use_atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
+                    else *dst = acc[i][j][r];
+                }
+            }
+#endif
+}
+
 // Column sums of a bf16 matrix in segments of `seg` rows: out[s][n] = sum_{m in segment s} y[m][n].
 // Used for bias gradients (one segment) and the timestep-embedding broadcast gradient (one segment
 // per sample).  Two stages without atomics: each block reduces a strip of rows to one partial row
@@ -242,7 +399,15 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
     a.tiles_co = (Cout + WG_BT - 1) / WG_BT;
     a.tiles_ci = (Cin + WG_BT - 1) / WG_BT;
     const int tiles = a.tiles_co * a.tiles_ci * a.taps;
-    const int nkt = (a.M + WG_BK - 1) / WG_BK;
+    // The LDS-DMA variant wins on long unsplit contractions (8192^3: 866 vs 821 TFLOP/s) but loses on the
+    // denoiser's split, im2col-addressed shapes (per-piece address arithmetic, short k-tiles), so the
+    // register-staged kernel stays the default; MI355_WGRAD_DMA=1 selects the DMA variant.
+    static const bool force_v1 = getenv("MI355_WGRAD_DMA") == nullptr;
+    const double dy_sz = (double)a.M * Cout * 2.0;
+    const double x_sz = (ksize == 1 && stride == 1 && !ups) ? (double)a.M * Cin * 2.0 : (double)B * H * W * Cin * 2.0;
+    const bool dma = !force_v1 && dy_sz < 2.0e9 && x_sz < 2.0e9;
+    const int bk = dma ? WD_BK : WG_BK;
+    const int nkt = (a.M + bk - 1) / bk;
     // split choice: waves of 512 co-resident workgroups, ~1 us per 64-pixel k-tile, fp32 atomics at ~1.3 TB/s
     int s = 1;
     {
@@ -253,7 +418,7 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
             const int kps = (nkt + c - 1) / c;
             if ((nkt + kps - 1) / kps != c) continue;
             const double waves = (double)((tiles * c + 511) / 512);
-            double t = waves * kps * 1.0;
+            double t = waves * kps * (dma ? 0.5 : 1.0);
             if (c > 1) { const double ta = c * out_bytes / 1.3e6; t = (t > ta ? t : ta) + 0.25 * (t < ta ? t : ta); }
             if (t < best_t) { best_t = t; s = c; }
         }
@@ -271,7 +436,10 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
     if (dbias && accumulate == 0 && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st) != hipSuccess)
         return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed");
     ProfScope prof(FAM_WGRAD, st, 2.0 * a.M * Cout * (double)a.taps * Cin);
-    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a);
+    if (dma)
+        hipLaunchKernelGGL(wgrad_dma_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a, (unsigned)dy_sz, (unsigned)x_sz);
+    else
+        hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a);
     return mi355_check_launch("wgrad_kernel");
 }
 
