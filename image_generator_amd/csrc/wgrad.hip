@@ -39,11 +39,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * 80, wn0 = (wave & 1) * 80;
 
+    // block order: taps fastest, then ci/co tiles, pixel split slowest - workgroups that run together (one
+    // XCD-contiguous chunk) read the SAME pixel range, so the dy tile and the (tap-shifted) x rows are
+    // served from that XCD's L2 instead of the fabric
     int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = lid % p.splits; lid /= p.splits;
+    const int tap = lid % p.taps; lid /= p.taps;
     const int tile_ci = lid % p.tiles_ci; lid /= p.tiles_ci;
     const int tile_co = lid % p.tiles_co;
-    const int tap = lid / p.tiles_co;
+    const int split = lid / p.tiles_co;
     const int co0 = tile_co * WG_BT, ci0 = tile_ci * WG_BT;
     int ky = 0, kx = 0;
     if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
@@ -208,11 +211,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p, un
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 80, wn0 = (wave & 1) * 80;
 
+    // block order: taps fastest, then ci/co tiles, pixel split slowest - workgroups that run together (one
+    // XCD-contiguous chunk) read the SAME pixel range, so the dy tile and the (tap-shifted) x rows are
+    // served from that XCD's L2 instead of the fabric
     int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = lid % p.splits; lid /= p.splits;
+    const int tap = lid % p.taps; lid /= p.taps;
     const int tile_ci = lid % p.tiles_ci; lid /= p.tiles_ci;
     const int tile_co = lid % p.tiles_co;
-    const int tap = lid / p.tiles_co;
+    const int split = lid / p.tiles_co;
     const int co0 = tile_co * WG_BT, ci0 = tile_ci * WG_BT;
     int ky = 0, kx = 0;
     if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
