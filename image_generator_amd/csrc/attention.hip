@@ -24,6 +24,8 @@ struct AttnArgs {
     float scale;
 };
 
+// raw v_exp_f32 (arguments here are <= 0 or -inf; no denormal range handling needed)
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
 #define LDS_TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr))
 
 __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
@@ -101,25 +103,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             }
         }
         float mx = -INFINITY;
+        if (k0 + 64 > p.Nk) {            // only the last key tile can hold padded keys (wave-uniform branch)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= p.Nk) s[kb][r] = -INFINITY;
+                }
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = s[kb][r] * p.scale_log2;
-                if (key >= p.Nk) v = -INFINITY;
-                s[kb][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;      // scale > 0: max commutes with the scaling
         const float m_new = fmaxf(m, mx);
-        const float alpha = exp2f(m - m_new);
+        const float alpha = EXP2(m - m_new);
         float sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[kb][r] - m_new);
+                const float e = EXP2(fmaf(s[kb][r], p.scale_log2, -m_new));
                 s[kb][r] = e;
                 sum += e;
             }
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float pv = exp2f(s[r] * p.scale_log2 - Ls[qi]);
+            float pv = EXP2(fmaf(s[r], p.scale_log2, -Ls[qi]));
             if (!k_ok) pv = 0.f;
             const float dsv = pv * (dp[r] - Ls[32 + qi]);
             pf[r >> 3][r & 7] = (bf16_t)pv;
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float pv = exp2f(s[r] * p.scale_log2 - lse);
+                float pv = EXP2(fmaf(s[r], p.scale_log2, -lse));
                 if (key >= p.Nk) pv = 0.f;
                 dsf[r >> 3][r & 7] = (bf16_t)(pv * (dp[r] - dlt));
             }

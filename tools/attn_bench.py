@@ -1,0 +1,29 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from image_generator_amd.ops import AttentionFn
+d = "cuda:0"
+def run(B, H, N, D, T=None):
+    C = H * D
+    if T is None:
+        a = torch.randn(B, N, 3 * C, device=d).to(torch.bfloat16).requires_grad_(True); b = None; Nk = N
+    else:
+        a = torch.randn(B, N, C, device=d).to(torch.bfloat16).requires_grad_(True)
+        b = torch.randn(B, T, 2 * C, device=d).to(torch.bfloat16).requires_grad_(True); Nk = T
+    do = torch.randn(B, N, C, device=d).to(torch.bfloat16)
+    def f():
+        return AttentionFn.apply(a, b, None, H)
+    for _ in range(3): o = f(); o.backward(do)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    it = 10
+    e[0].record()
+    for _ in range(it): o = f()
+    e[1].record()
+    for _ in range(it): o.backward(do, retain_graph=True)
+    e[2].record(); torch.cuda.synchronize()
+    tf, tb = e[0].elapsed_time(e[1]) / it * 1e-3, e[1].elapsed_time(e[2]) / it * 1e-3
+    fl = 4.0 * B * H * N * Nk * D
+    print(f"B{B} H{H} N{N} Nk{Nk} D{D}: fwd {tf*1e6:8.1f} us {fl/tf/1e12:6.1f} TF | bwd {tb*1e6:8.1f} us {2.5*fl/tb/1e12:6.1f} TF")
+run(32, 8, 1024, 40); run(32, 8, 256, 80); run(32, 8, 64, 160); run(32, 8, 1024, 40, 77); run(32, 8, 256, 80, 77)
+run(32, 8, 4096, 40); run(32, 8, 1024, 80); run(32, 8, 256, 160)

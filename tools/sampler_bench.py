@@ -1,0 +1,78 @@
+"""BASELINE configs 4 and 5 on one MI355X (run on the GPU box):
+  --mode sampler : 512x512 sampling loop, 16 images with classifier-free guidance (UNet batch 32), DDIM,
+                   one HIP graph per step shape; reports sampler steps/s and the MFMA fraction
+                   (25.7 TFLOP per step)
+  --mode lora    : LoRA fine-tune step at 256x256, batch 32 (frozen base, rank-4 adapters on
+                   attn{1,2}.to_{q,k,v,out}); reports images/s
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def sampler(args):
+    from image_generator_amd.generator import ImageGenerator
+    torch.manual_seed(0)
+    gen = ImageGenerator("cuda:0", text_encoder_kwargs=dict(num_layers=2))     # text tower depth is irrelevant here
+    gen.eval()
+    n, side = args.images, args.res // 8
+    emb = torch.randn(2 * n, 77, 768, device="cuda:0").to(torch.bfloat16)
+    lat = torch.randn(n, 4, side, side, device="cuda:0")
+    for use_graph in (False, True):
+        gen.sample_latents(emb, lat, 3, 7.5, use_graph=use_graph)            # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = gen.sample_latents(emb, lat, args.steps, 7.5, use_graph=use_graph)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        flops = 2 * n * 803.9e9 * (side / 64.0) ** 2
+        print(json.dumps({"mode": "sampler", "hip_graph": use_graph, "images": n, "res": args.res, "steps": args.steps,
+                          "steps_per_s": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                          "mfma_frac": flops * args.steps / dt / 2.5e15, "finite": bool(torch.isfinite(out).all())}))
+
+
+def lora(args):
+    from image_generator_amd.generator import inject_lora
+    from image_generator_amd.ops import mse_loss
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    torch.manual_seed(0)
+    with torch.device("cuda:0"):
+        unet = UNet2DConditionModel(DenoiserConfig.sd_v1())
+    adapters = inject_lora(unet, r=4, alpha=1.0)
+    unet.to("cuda:0")
+    params = [p for p in unet.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-2, foreach=True)
+    B = args.batch
+    lat, noise = torch.randn(B, 4, 32, 32, device="cuda:0"), torch.randn(B, 4, 32, 32, device="cuda:0")
+    ts = torch.randint(0, 1000, (B,), device="cuda:0")
+    ctx = torch.randn(B, 77, 768, device="cuda:0").to(torch.bfloat16)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = mse_loss(unet(lat, ts, encoder_hidden_states=ctx).sample, noise)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"mode": "lora", "adapters": len(adapters), "trainable_params": sum(p.numel() for p in params),
+                      "batch": B, "images_per_s": B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                      "loss": float(loss)}))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="sampler")
+    ap.add_argument("--images", type=int, default=16)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=32)
+    a = ap.parse_args()
+    (sampler if a.mode == "sampler" else lora)(a)
