@@ -31,8 +31,7 @@ constexpr int WG_BK = 64;           // pixels per k tile
 constexpr int WG_LD = 352;          // LDS row stride in bytes
 constexpr int WG_CH = 5;            // 16-byte chunks per thread per operand
 
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * WG_BK * WG_LD];
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_id, const int grid_blocks, char* smem) {
     char* As = smem;                       // dy tile  [64][160]
     char* Bs = smem + WG_BK * WG_LD;       // x tile   [64][160]
 
@@ -42,11 +41,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     // block order: taps fastest, then ci/co tiles, pixel split slowest - workgroups that run together (one
     // XCD-contiguous chunk) read the SAME pixel range, so the dy tile and the (tap-shifted) x rows are
     // served from that XCD's L2 instead of the fabric
-    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(block_id, grid_blocks);
     const int tap = lid % p.taps; lid /= p.taps;
     const int tile_ci = lid % p.tiles_ci; lid /= p.tiles_ci;
     const int tile_co = lid % p.tiles_co;
     const int split = lid / p.tiles_co;
+    if (split >= p.splits) return;          // padding block of a grouped launch
     const int co0 = tile_co * WG_BT, ci0 = tile_ci * WG_BT;
     int ky = 0, kx = 0;
     if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
@@ -180,6 +180,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
                     else *dst = acc[i][j][r];
                 }
             }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * WG_BK * WG_LD];
+    wgrad_body(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Many independent weight-gradient problems in ONE launch (deferred from the backward pass): job j owns
+// blocks [first_block_j, first_block_{j+1}), padded to a multiple of 8 so the XCD-aware block order of
+// each job is preserved.  With thousands of tiles in flight no job needs an aggressive pixel split, so
+// atomic traffic drops and small layers no longer run alone on a mostly idle chip.
+struct WgradJob {
+    WgradArgs a;
+    int first_block;
+    int nblocks;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_grouped_kernel(const WgradJob* __restrict__ jobs, int njobs) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * WG_BK * WG_LD];
+    int lo = 0, hi = njobs - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {                           // wave-uniform binary search over the block prefix
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+    }
+    const WgradJob& j = jobs[lo];
+    WgradArgs p = j.a;
+    wgrad_body(p, bid - j.first_block, j.nblocks, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,6 +419,52 @@ static void colsum_geometry(int M, int N, int seg, int* rows_per_block, int* chu
 }
 
 extern "C" {
+
+static void wgrad_plan(WgradArgs& a, int B, int Cin, int Cout, int ksize, int Ho, int Wo, int target_kt) {
+    a.M = B * Ho * Wo; a.Cout = Cout; a.Cin = Cin;
+    a.taps = ksize * ksize;
+    a.tiles_co = (Cout + WG_BT - 1) / WG_BT;
+    a.tiles_ci = (Cin + WG_BT - 1) / WG_BT;
+    const int nkt = (a.M + WG_BK - 1) / WG_BK;
+    int s = (nkt + target_kt - 1) / target_kt;
+    if (s < 1) s = 1;
+    a.kt_per_split = (nkt + s - 1) / s;
+    a.splits = (nkt + a.kt_per_split - 1) / a.kt_per_split;
+}
+
+int mi355_wgrad_job_bytes(void) { return (int)sizeof(WgradJob); }
+
+// Fills one job record in HOST memory (mi355_wgrad_job_bytes() bytes).  dw (and dbias) must have been
+// zeroed by the caller when the job is split (the record says so through *splits_out).  Returns the
+// number of blocks the job occupies in the grouped launch (a multiple of 8), or a negative error.
+int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W,
+                         int Cin, int Cout, int ksize, int stride, int ups, int Ho, int Wo, int first_block,
+                         int* splits_out) {
+    if (!host_job || !dy || !x || !dw) return mi355_fail(MI355_ERR_ARG, "wgrad_job_fill: null pointer");
+    if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "wgrad_job_fill: ksize %d", ksize);
+    if ((Cin & 7) || (Cout & 7)) return mi355_fail(MI355_ERR_ARG, "wgrad_job_fill: channels must be multiples of 8");
+    WgradJob* j = (WgradJob*)host_job;
+    WgradArgs& a = j->a;
+    a = WgradArgs{};
+    a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.dw = dw; a.dbias = dbias;
+    a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ups = ups; a.ksize = ksize; a.ldx = Cin;
+    wgrad_plan(a, B, Cin, Cout, ksize, Ho, Wo, 64);
+    a.use_atomic = a.splits > 1 ? 1 : 0;
+    const int blocks = a.tiles_co * a.tiles_ci * a.taps * a.splits;
+    j->first_block = first_block;
+    j->nblocks = (blocks + 7) & ~7;
+    if (splits_out) *splits_out = a.splits;
+    return j->nblocks;
+}
+
+// jobs: DEVICE copy of njobs records; total_blocks = sum of their block counts.
+int mi355_wgrad_grouped(const void* jobs, int njobs, int total_blocks, double flops, void* stream) {
+    if (!jobs || njobs <= 0 || total_blocks <= 0) return mi355_fail(MI355_ERR_ARG, "wgrad_grouped: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(FAM_WGRAD, st, flops);
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total_blocks), dim3(256), 0, st, (const WgradJob*)jobs, njobs);
+    return mi355_check_launch("wgrad_grouped_kernel");
+}
 
 int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
                      int ksize, int stride, int ups, int Ho, int Wo, int accumulate, void* stream) {

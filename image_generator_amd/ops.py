@@ -5,6 +5,7 @@ libmi355_denoiser.so.  Activations are bf16, token-major / NHWC.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import torch
@@ -97,6 +98,75 @@ def wgrad(dy, x, cin, cout, ksize=1, stride=1, ups=False, geom=None, out=None, a
     check(lib.mi355_wgrad_bf16(dy.data_ptr(), x.data_ptr(), out.data_ptr(), _ptr(dbias), B, H, W, cin, cout, ksize, stride,
                                int(ups), Ho, Wo, int(accumulate), _stream()), "wgrad")
     return out
+
+
+class WgradQueue:
+    """Deferred weight gradients: backward pushes (dy, x, destination) jobs, `flush()` runs them as ONE
+    grouped launch.  Thousands of tiles in flight keep all 256 CUs busy without aggressive pixel splits
+    (less atomic traffic) and remove ~230 small launches per step.  Destinations must be pre-zeroed."""
+
+    def __init__(self, device, flush_blocks=4096, max_jobs=512, ring=64):
+        self.device = device
+        self.jb = int(lib.mi355_wgrad_job_bytes())
+        self.max_jobs, self.flush_blocks = max_jobs, flush_blocks
+        self._ring = [torch.empty(max_jobs * self.jb, dtype=torch.uint8).pin_memory() for _ in range(ring)]
+        self._ri = 0
+        self._ring_size = ring
+        self._keep = []          # pinned tables referenced by captured graphs (must outlive them)
+        self._host = self._ring[0]
+        self._n = 0
+        self._blocks = 0
+        self._flops = 0.0
+        self._refs = []
+        self._cbs = []
+        self._splits = ctypes.c_int(0)
+
+    def push(self, dy, x, dw, dbias, B, H, W, cin, cout, ksize, stride, ups, Ho, Wo, callback=None):
+        nb = lib.mi355_wgrad_job_fill(self._host.data_ptr() + self._n * self.jb, dy.data_ptr(), x.data_ptr(),
+                                      dw.data_ptr(), _ptr(dbias), B, H, W, cin, cout, ksize, stride, int(ups), Ho, Wo,
+                                      self._blocks, ctypes.byref(self._splits))
+        check(min(nb, 0), "wgrad_job_fill")
+        self._n += 1
+        self._blocks += nb
+        self._flops += 2.0 * B * Ho * Wo * cout * ksize * ksize * cin
+        self._refs.append((dy, x))
+        if callback is not None:
+            self._cbs.append(callback)
+        if self._blocks >= self.flush_blocks or self._n == self.max_jobs:
+            self.flush()
+
+    def flush(self):
+        if self._n == 0:
+            return
+        nbytes = self._n * self.jb
+        table = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        table.copy_(self._host[:nbytes], non_blocking=True)
+        check(lib.mi355_wgrad_grouped(table.data_ptr(), self._n, self._blocks, self._flops, _stream()), "wgrad_grouped")
+        for cb in self._cbs:
+            cb()
+        if torch.cuda.is_current_stream_capturing():
+            # the graph re-reads this table on every replay: retire it from the ring (host memory cannot be
+            # pinned while a capture is open, so the ring is refilled by the next eager flush)
+            self._keep.append(self._ring.pop(self._ri))
+            if not self._ring:
+                raise RuntimeError("WgradQueue: pinned table ring exhausted during graph capture")
+            self._ri %= len(self._ring)
+        else:
+            while len(self._ring) < self._ring_size:
+                self._ring.append(torch.empty(self.max_jobs * self.jb, dtype=torch.uint8).pin_memory())
+            self._ri = (self._ri + 1) % len(self._ring)
+        self._host = self._ring[self._ri]
+        self._n, self._blocks, self._flops = 0, 0, 0.0
+        self._refs, self._cbs = [], []
+
+
+_WGRAD_QUEUE = None
+
+
+def set_wgrad_queue(q):
+    """Install (or remove with None) the queue used by layers in direct-gradient mode."""
+    global _WGRAD_QUEUE
+    _WGRAD_QUEUE = q
 
 
 def colsum(y2d, seg=None):
@@ -198,10 +268,14 @@ class LinearFn(torch.autograd.Function):
                 # direct mode: the owner zeroed the flat gradient buffer; gradients are written in place
                 if want_db and pack.bias_grad_out is None:
                     db = torch.zeros(pack.n, dtype=F32, device=dy2.device)
-                wgrad(dy2, x2, pack.k, pack.n, out=pack.grad_out, accumulate=2,
-                      dbias=(pack.bias_grad_out if pack.bias_grad_out is not None else db) if want_db else None)
-                if pack.on_grad_ready is not None:
-                    pack.on_grad_ready()
+                dbias = (pack.bias_grad_out if pack.bias_grad_out is not None else db) if want_db else None
+                if _WGRAD_QUEUE is not None:
+                    _WGRAD_QUEUE.push(dy2, x2, pack.grad_out, dbias, dy2.shape[0], 1, 1, pack.k, pack.n, 1, 1, False, 1, 1,
+                                      pack.on_grad_ready)
+                else:
+                    wgrad(dy2, x2, pack.k, pack.n, out=pack.grad_out, accumulate=2, dbias=dbias)
+                    if pack.on_grad_ready is not None:
+                        pack.on_grad_ready()
             else:
                 if want_db:
                     db = torch.empty(pack.n, dtype=F32, device=dy2.device)
@@ -258,10 +332,15 @@ class ConvFn(torch.autograd.Function):
                 direct_b = want_db and pack.bias_grad_out is not None
                 if want_db and not direct_b:
                     dbp = torch.zeros(pack.cout_pad, dtype=F32, device=dy.device)
-                wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=geom, out=pack.grad_out,
-                      accumulate=2, dbias=(pack.bias_grad_out if direct_b else dbp) if want_db else None)
-                if pack.on_grad_ready is not None:
-                    pack.on_grad_ready()
+                dbias = (pack.bias_grad_out if direct_b else dbp) if want_db else None
+                if _WGRAD_QUEUE is not None:
+                    _WGRAD_QUEUE.push(dy, x, pack.grad_out, dbias, B, H, W, pack.cin_pad, pack.cout_pad, pack.ksize, stride,
+                                      ups, Ho, Wo, pack.on_grad_ready)
+                else:
+                    wgrad(dy, x, pack.cin_pad, pack.cout_pad, pack.ksize, stride, ups, geom=geom, out=pack.grad_out,
+                          accumulate=2, dbias=dbias)
+                    if pack.on_grad_ready is not None:
+                        pack.on_grad_ready()
             else:
                 if want_db:
                     dbp = torch.empty(pack.cout_pad, dtype=F32, device=dy.device)

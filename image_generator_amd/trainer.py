@@ -190,6 +190,9 @@ class DenoiserTrainer:
             alphas_cumprod = sd_alphas_cumprod()
         self.acp = alphas_cumprod.to(device=dev, dtype=F32).contiguous()
         self.base_lr = lr
+        from . import ops as _ops
+        self._ops = _ops
+        self.wgrad_queue = _ops.WgradQueue(dev) if os.environ.get("MI355_NO_WGRAD_QUEUE") != "1" else None
 
     def forward_backward(self, latents, noise, t, ctx):
         B = latents.shape[0]
@@ -199,7 +202,13 @@ class DenoiserTrainer:
         self.unet.zero_small_grads()
         pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
         loss = mse_loss(pred, noise)
-        loss.backward()
+        self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched
+        try:
+            loss.backward()
+            if self.wgrad_queue is not None:
+                self.wgrad_queue.flush()
+        finally:
+            self._ops.set_wgrad_queue(None)
         if self.reducer is not None:
             self.reducer.finish()
         return loss.detach()

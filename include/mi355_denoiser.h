@@ -69,6 +69,15 @@ int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, 
 int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
                      int ksize, int stride, int ups, int Ho, int Wo, int accumulate, void* stream);
 
+/* Deferred, batched weight gradients: fill job records on the host, copy them to the device, launch once.
+ * mi355_wgrad_job_fill returns the job's block count (multiple of 8); first_block = running sum of them.
+ * dw/dbias of every job must be zero before the launch (split jobs and bias sums accumulate atomically). */
+int mi355_wgrad_job_bytes(void);
+int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W,
+                         int Cin, int Cout, int ksize, int stride, int ups, int Ho, int Wo, int first_block,
+                         int* splits_out);
+int mi355_wgrad_grouped(const void* jobs, int njobs, int total_blocks, double flops, void* stream);
+
 /* out[s][n] = sum of the rows of segment s (seg rows each) of y[M][N] (bias / broadcast gradients). */
 long long mi355_colsum_scratch_floats(int M, int N, int seg);
 int mi355_colsum_bf16(const void* y, float* out, float* scratch, int M, int N, int seg, void* stream);
