@@ -11,7 +11,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libmi355_denoiser.so")
+# MI355_DENOISER_LIB selects another build of the same ABI (A/B comparisons of kernel variants)
+LIB_PATH = os.environ.get("MI355_DENOISER_LIB") or os.path.join(_HERE, "libmi355_denoiser.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "mi355_denoiser.h")
 
 _CTYPES = {

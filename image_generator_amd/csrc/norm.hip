@@ -5,10 +5,12 @@
 // 8-channel chunk for a strip of pixels, so reads are fully coalesced rows regardless of the group
 // width (C/32 is 10..80 channels in this network and is not a multiple of the vector width).
 //
-//   forward :  chan_sums (sum x, sum x^2 per (b,c), atomics)  ->  gn_finalize (mean, rstd per (b,g))
-//              ->  gn_apply  (y = silu?(x*scale + shift))
-//   backward:  chan_sums (sum dz, sum dz*xhat per (b,c))      ->  gn_bwd_finalize (group sums, dgamma, dbeta)
-//              ->  gn_bwd_apply (dx)
+//   forward :  gn_partial<0> (per (b, pixel strip): sum x, sum x^2 per group)
+//              ->  gn_apply  (prologue: strips -> mean, rstd per group;  y = silu?(x*scale + shift))
+//   backward:  gn_partial<1> (per (b, strip): sum dz, sum dz*xhat per channel, and gamma-weighted per group)
+//              ->  gn_bwd_apply (prologue: strips -> group means;  dx)   +   gn_param_grads (dgamma, dbeta)
+// No atomics and no stand-alone finalize kernels: the few hundred partial sums a block needs are re-reduced
+// in its prologue, which is cheaper than a dependent launch.
 #include "common.h"
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
@@ -18,12 +20,14 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 }
 
 // MODE 0: acc0 += x, acc1 += x^2.   MODE 1: dz = dy * act'(z); acc0 += dz, acc1 += dz * xhat.
-// grid = (strips, B); blockDim.x = nc * rows_par (nc = C/8).  sums: per-strip partials [B][strips][C][2] fp32.
+// grid = (strips, B); blockDim.x = nc * rows_par (nc = C/8).
+// gpart [B][strips][G][2]: per-group sums of this strip (MODE 1: weighted by gamma).
+// cpart [B][strips][C][2]: per-channel sums (MODE 1 only; feeds dgamma / dbeta).
 template <int MODE>
-__global__ void gn_chan_sums_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                    const float* __restrict__ stats, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, float* __restrict__ sums, int HW, int C, int G,
-                                    int rows_per_block, int silu) {
+__global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                  const float* __restrict__ stats, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* __restrict__ gpart, float* __restrict__ cpart,
+                                  int HW, int C, int G, int rows_per_block, int silu) {
     const int nc = C >> 3;
     const int b = blockIdx.y;
     const int c8 = threadIdx.x % nc, rp = threadIdx.x / nc, rpar = blockDim.x / nc;
@@ -60,71 +64,84 @@ __global__ void gn_chan_sums_kernel(const bf16_t* __restrict__ x, const bf16_t* 
             }
         }
     }
-    // combine the row phases of this block through LDS, then one atomic per (channel, stat)
+    // combine the row phases of this block through LDS
     extern __shared__ float red[];   // [rpar][nc][16]
     float* mine = red + ((size_t)rp * nc + c8) * 16;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { mine[e] = a0[e]; mine[8 + e] = a1[e]; }
     __syncthreads();
+    const size_t slot = (size_t)b * gridDim.x + blockIdx.x;
     if (rp == 0) {
         for (int q = 1; q < rpar; ++q) {
             const float* o = red + ((size_t)q * nc + c8) * 16;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a0[e] += o[e]; a1[e] += o[8 + e]; }
         }
-        // per-strip partial (plain stores; a second kernel sums the strips - no contended atomics)
-        float* dst = sums + (((size_t)b * gridDim.x + blockIdx.x) * C + c8 * 8) * 2;
+        if (MODE == 1) {
+            float* dst = cpart + (slot * C + c8 * 8) * 2;
 #pragma unroll
-        for (int e = 0; e < 8; e += 2)
-            *(f32x4*)(dst + 2 * e) = f32x4{a0[e], a1[e], a0[e + 1], a1[e + 1]};
+            for (int e = 0; e < 8; e += 2)
+                *(f32x4*)(dst + 2 * e) = f32x4{a0[e], a1[e], a0[e + 1], a1[e + 1]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] *= sc[e]; a1[e] *= sc[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mine[e] = a0[e]; mine[8 + e] = a1[e]; }     // rp == 0: mine = red[c8][16]
+    }
+    __syncthreads();
+    // channels -> groups (a group is C/G channels, not a multiple of the 8-channel chunk in general)
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) { s0 += red[(c >> 3) * 16 + (c & 7)]; s1 += red[(c >> 3) * 16 + 8 + (c & 7)]; }
+        gpart[(slot * G + g) * 2] = s0;
+        gpart[(slot * G + g) * 2 + 1] = s1;
     }
 }
 
-// sums[b][c][k] = sum over strips of partial[b][strip][c][k]   (one thread per (b, c, k))
-__global__ void gn_reduce_strips_kernel(const float* __restrict__ partial, float* __restrict__ sums, int B, int C,
-                                        int strips) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C * 2) return;
-    const int b = i / (C * 2), r = i - b * C * 2;
-    float s = 0.f;
-    for (int t = 0; t < strips; ++t) s += partial[((size_t)b * strips + t) * C * 2 + r];
-    sums[i] = s;
+// Sums the strips' group partials of sample b into LDS: gs[g] = {sum0, sum1}.  Every thread of the block calls it.
+__device__ __forceinline__ void gn_group_sums(const float* __restrict__ gpart, float* gs, int b, int strips, int G) {
+    for (int i = threadIdx.x; i < G * 2; i += blockDim.x) {
+        const float* src = gpart + (size_t)b * strips * G * 2 + i;
+        float s = 0.f;
+        for (int t = 0; t < strips; ++t) s += src[(size_t)t * G * 2];
+        gs[i] = s;
+    }
+    __syncthreads();
 }
 
-// one thread per (b, g)
-__global__ void gn_finalize_kernel(const float* __restrict__ sums, float* __restrict__ stats, int B, int C, int G,
-                                   int HW, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * G) return;
-    const int b = i / G, g = i - b * G, cg = C / G;
-    float s = 0.f, ss = 0.f;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) { s += sums[((size_t)b * C + c) * 2]; ss += sums[((size_t)b * C + c) * 2 + 1]; }
-    const float n = (float)HW * cg;
-    const float mean = s / n;
-    float var = ss / n - mean * mean;
-    if (var < 0.f) var = 0.f;
-    stats[(size_t)i * 2] = mean;
-    stats[(size_t)i * 2 + 1] = rsqrtf(var + eps);
-}
-
-__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gpart, float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                bf16_t* __restrict__ y, int HW, int C, int G, int rows_per_block, int silu) {
+                                bf16_t* __restrict__ y, int HW, int C, int G, int rows_per_block, int silu, float eps) {
+    extern __shared__ float gs[];            // [G][2] -> mean, rstd
     const int nc = C >> 3;
     const int b = blockIdx.y;
-    const int c8 = threadIdx.x % nc, rp = threadIdx.x / nc, rpar = blockDim.x / nc;
-    const int r_begin = blockIdx.x * rows_per_block;
-    int r_end = r_begin + rows_per_block;
-    if (r_end > HW) r_end = HW;
     const int cg = C / G;
+    gn_group_sums(gpart, gs, b, gridDim.x, G);
+    const float inv_n = 1.f / ((float)HW * cg);
     float sc[8], sh[8];
+    const int c8 = threadIdx.x % nc, rp = threadIdx.x / nc, rpar = blockDim.x / nc;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = c8 * 8 + e, g = c / cg;
-        const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
+        const float mean = gs[g * 2] * inv_n;
+        float var = gs[g * 2 + 1] * inv_n - mean * mean;
+        if (var < 0.f) var = 0.f;
+        const float rstd = rsqrtf(var + eps);
         sc[e] = rstd * gamma[c];
         sh[e] = beta[c] - mean * sc[e];
     }
+    if (blockIdx.x == 0) {                   // one block per sample publishes the statistics for the backward pass
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            const float mean = gs[g * 2] * inv_n;
+            float var = gs[g * 2 + 1] * inv_n - mean * mean;
+            if (var < 0.f) var = 0.f;
+            stats[((size_t)b * G + g) * 2] = mean;
+            stats[((size_t)b * G + g) * 2 + 1] = rsqrtf(var + eps);
+        }
+    }
+    const int r_begin = blockIdx.x * rows_per_block;
+    int r_end = r_begin + rows_per_block;
+    if (r_end > HW) r_end = HW;
     const size_t base = (size_t)b * HW * C + c8 * 8;
     for (int r = r_begin + rp; r < r_end; r += rpar) {
         const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)r * C);
@@ -139,37 +156,46 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
     }
 }
 
-// one thread per (b,g): gsum[b][g] = {sum_c gamma*dbeta_bc, sum_c gamma*dgamma_bc}; block (0) threads also
-// reduce dgamma/dbeta over the batch.  sums: [B][C][2] = {sum dz, sum dz*xhat}.
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
-                                       float* __restrict__ gsum, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int B, int C, int G) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int cg = C / G;
-    if (i < B * G) {
-        const int b = i / G, g = i - b * G;
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) {
-            s1 += gamma[c] * sums[((size_t)b * C + c) * 2];
-            s2 += gamma[c] * sums[((size_t)b * C + c) * 2 + 1];
+// dgamma[c], dbeta[c] = sums over all (sample, strip) rows of cpart[row][c][1], cpart[row][c][0].
+// grid = ceil(C/64), 256 threads = 64 channels x 4 row phases.
+__global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __restrict__ cpart, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int rows, int C) {
+    __shared__ float red[4][64][2];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        const float* src = cpart + (size_t)c * 2;
+        int r = ph;
+        for (; r + 12 < rows; r += 16) {
+            const float2 v0 = *(const float2*)(src + (size_t)r * C * 2);
+            const float2 v1 = *(const float2*)(src + (size_t)(r + 4) * C * 2);
+            const float2 v2 = *(const float2*)(src + (size_t)(r + 8) * C * 2);
+            const float2 v3 = *(const float2*)(src + (size_t)(r + 12) * C * 2);
+            s0 += (v0.x + v1.x) + (v2.x + v3.x);
+            s1 += (v0.y + v1.y) + (v2.y + v3.y);
         }
-        gsum[(size_t)i * 2] = s1;
-        gsum[(size_t)i * 2 + 1] = s2;
+        for (; r < rows; r += 4) {
+            const float2 v = *(const float2*)(src + (size_t)r * C * 2);
+            s0 += v.x; s1 += v.y;
+        }
     }
-    if (i < C) {
-        float db = 0.f, dg = 0.f;
-        for (int b = 0; b < B; ++b) { db += sums[((size_t)b * C + i) * 2]; dg += sums[((size_t)b * C + i) * 2 + 1]; }
-        dbeta[i] = db;
-        dgamma[i] = dg;
+    red[ph][cl][0] = s0; red[ph][cl][1] = s1;
+    __syncthreads();
+    if (ph == 0 && c < C) {
+        dbeta[c] = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+        dgamma[c] = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
     }
 }
 
 __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                    const float* __restrict__ stats, const float* __restrict__ gsum,
+                                    const float* __restrict__ stats, const float* __restrict__ gpart,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     bf16_t* __restrict__ dx, int HW, int C, int G, int rows_per_block, int silu) {
+    extern __shared__ float gs[];            // [G][2] = {sum_c gamma*sum dz, sum_c gamma*sum dz*xhat}
     const int nc = C >> 3;
     const int b = blockIdx.y;
+    gn_group_sums(gpart, gs, b, gridDim.x, G);
     const int c8 = threadIdx.x % nc, rp = threadIdx.x / nc, rpar = blockDim.x / nc;
     const int r_begin = blockIdx.x * rows_per_block;
     int r_end = r_begin + rows_per_block;
@@ -184,8 +210,8 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
         rs[e] = stats[((size_t)b * G + g) * 2 + 1];
         ga[e] = gamma[c];
         be[e] = beta[c];
-        m1[e] = gsum[((size_t)b * G + g) * 2] * inv_n;
-        m2[e] = gsum[((size_t)b * G + g) * 2 + 1] * inv_n;
+        m1[e] = gs[g * 2] * inv_n;
+        m2[e] = gs[g * 2 + 1] * inv_n;
     }
     const size_t base = (size_t)b * HW * C + c8 * 8;
     for (int r = r_begin + rp; r < r_end; r += rpar) {
@@ -347,7 +373,7 @@ extern "C" {
 long long mi355_groupnorm_scratch_floats(int B, int HW, int C, int G) {
     int threads, rpar, rows, strips;
     if (gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return -1;
-    return (long long)B * strips * C * 2 + (long long)B * C * 2 + (long long)B * G * 2;
+    return (long long)B * strips * C * 2 + (long long)B * strips * G * 2;
 }
 
 // scratch: mi355_groupnorm_scratch_floats().  stats out: [B][G][2] = mean, rstd.
@@ -357,16 +383,13 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    float* partial = scratch;
-    float* sums = scratch + (size_t)B * strips * C * 2;
+    float* gpart = scratch;
     ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 3);
     const size_t sh = (size_t)threads * 16 * sizeof(float);
-    hipLaunchKernelGGL(gn_chan_sums_kernel<0>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x, nullptr,
-                       nullptr, nullptr, nullptr, partial, HW, C, G, rows, 0);
-    hipLaunchKernelGGL(gn_reduce_strips_kernel, dim3((B * C * 2 + 255) / 256), dim3(256), 0, st, partial, sums, B, C, strips);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, sums, stats, B, C, G, HW, eps);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(strips, B), dim3(threads), 0, st, (const bf16_t*)x, stats, gamma, beta,
-                       (bf16_t*)y, HW, C, G, rows, silu);
+    hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x, nullptr,
+                       nullptr, nullptr, nullptr, gpart, nullptr, HW, C, G, rows, 0);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st, (const bf16_t*)x,
+                       gpart, stats, gamma, beta, (bf16_t*)y, HW, C, G, rows, silu, eps);
     return mi355_check_launch("groupnorm_fwd");
 }
 
@@ -379,19 +402,15 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    float* partial = scratch;
-    float* sums = scratch + (size_t)B * strips * C * 2;
-    float* gsum = sums + (size_t)B * C * 2;
+    float* gpart = scratch;
+    float* cpart = scratch + (size_t)B * strips * G * 2;
     ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 5);
     const size_t sh = (size_t)threads * 16 * sizeof(float);
-    hipLaunchKernelGGL(gn_chan_sums_kernel<1>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x,
-                       (const bf16_t*)dy, stats, gamma, beta, partial, HW, C, G, rows, silu);
-    hipLaunchKernelGGL(gn_reduce_strips_kernel, dim3((B * C * 2 + 255) / 256), dim3(256), 0, st, partial, sums, B, C, strips);
-    const int nfin = B * G > C ? B * G : C;
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nfin + 255) / 256), dim3(256), 0, st, sums, gamma, gsum, dgamma,
-                       dbeta, B, C, G);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(strips, B), dim3(threads), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       stats, gsum, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu);
+    hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x,
+                       (const bf16_t*)dy, stats, gamma, beta, gpart, cpart, HW, C, G, rows, silu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st,
+                       (const bf16_t*)x, (const bf16_t*)dy, stats, gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu);
+    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 63) / 64), dim3(256), 0, st, cpart, dgamma, dbeta, B * strips, C);
     return mi355_check_launch("groupnorm_bwd");
 }
 

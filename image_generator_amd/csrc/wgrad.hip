@@ -24,6 +24,9 @@ struct WgradArgs {
     int use_atomic;
     int ldx;            // dense: row stride of x
     float* dbias;       // optional [Cout] fp32, pre-zeroed: column sums of dy (bias gradient), or null
+    unsigned dy_bytes, x_bytes;   // extents of dy / x for the LDS-DMA loader's buffer descriptors (< 2 GiB)
+    int lw, lh;         // log2(Wo), log2(Ho) when both are powers of two, else -1
+    int nmain;          // LDS-DMA launch: number of workgroups that have work (a grouped launch pads each job)
 };
 
 constexpr int WG_BT = 160;          // channels per tile side
@@ -46,7 +49,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_i
     const int tile_ci = lid % p.tiles_ci; lid /= p.tiles_ci;
     const int tile_co = lid % p.tiles_co;
     const int split = lid / p.tiles_co;
-    if (split >= p.splits) return;          // padding block of a grouped launch
+    if (split >= p.splits) return;
     const int co0 = tile_co * WG_BT, ci0 = tile_ci * WG_BT;
     int ky = 0, kx = 0;
     if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
@@ -187,35 +190,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     wgrad_body(p, blockIdx.x, gridDim.x, smem);
 }
 
-// Many independent weight-gradient problems in ONE launch (deferred from the backward pass): job j owns
-// blocks [first_block_j, first_block_{j+1}), padded to a multiple of 8 so the XCD-aware block order of
-// each job is preserved.  With thousands of tiles in flight no job needs an aggressive pixel split, so
-// atomic traffic drops and small layers no longer run alone on a mostly idle chip.
-struct WgradJob {
-    WgradArgs a;
-    int first_block;
-    int nblocks;
-};
-
-__global__ __launch_bounds__(256, 2) void wgrad_grouped_kernel(const WgradJob* __restrict__ jobs, int njobs) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * WG_BK * WG_LD];
-    int lo = 0, hi = njobs - 1;
-    const int bid = blockIdx.x;
-    while (lo < hi) {                           // wave-uniform binary search over the block prefix
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
-    }
-    const WgradJob& j = jobs[lo];
-    WgradArgs p = j.a;
-    wgrad_body(p, bid - j.first_block, j.nblocks, smem);
-}
-
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA variant of the weight-gradient kernel.  Tiles of 32 pixels x 160 channels per operand are
-// written to LDS by `buffer_load ... lds` in a linear [pixel][176-channel] image (the 16 spare channels
-// per row are fetched out of range = zeros; they give the 352-byte row stride the transposing reads
-// need).  Two LDS stages of 22.5 KB, one barrier per k-tile, next tile's DMA in flight under the MFMAs.
+// LDS-DMA weight-gradient body (the default).  Tiles of 32 pixels x 160 channels per operand are written
+// to LDS by `buffer_load ... lds` in a linear [pixel][176-channel] image (the 16 spare channels per row
+// are fetched out of range = zeros; they give the 352-byte row stride the transposing reads need).  Three
+// LDS stages of 22 KB, one barrier per k-tile, the next two tiles' DMA in flight under the MFMAs.
 // Out-of-range pixels / padding taps / channels beyond the tensor use an out-of-range buffer offset.
+//
+// Addressing is incremental: every lane owns the same (pixel row, channel chunk) slot of each of its
+// pieces for the whole contraction, and for stride-1 taps the source offset is LINEAR in the pixel
+// index (pixel m reads pixel m + (ky-1)*W + (kx-1)), so a k-tile costs one add per piece plus the border
+// test - the divisions by Wo/Ho of a naive im2col gather would otherwise outweigh the 25 MFMAs a wave
+// issues per k-tile.  Strided and upsampled taps keep the generic gather.
 // ---------------------------------------------------------------------------------------------
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr int WD_BK = 32;                       // pixels per k-tile
@@ -223,6 +209,21 @@ constexpr int WD_CHUNKS = 22;                   // 16-byte chunks per LDS row (2
 constexpr int WD_TILE = WD_BK * WG_LD;          // bytes per operand tile (11 KiB pieces)
 constexpr int WD_PIECES = WD_BK * WD_CHUNKS / 64;   // 11 per operand
 constexpr int OOB_OFF = (int)0x80000000;
+
+// Transposing LDS read issued as inline asm: the compiler makes an LDS read it knows about wait for EVERY
+// outstanding `buffer_load ... lds` (vmcnt(0)), which would serialise the DMA prefetch with the MFMAs.  The
+// caller waits with lds_wait() before the first use of the results.
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_tr(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait(bf16x4 (&a)[5], bf16x4 (&b)[5]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4])
+                 :: "memory");
+}
 
 __device__ __forceinline__ int fast_div(int n, int d, float rd) {
     int q = (int)((float)n * rd);
@@ -232,9 +233,10 @@ __device__ __forceinline__ int fast_div(int n, int d, float rd) {
     return q;
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p, unsigned dy_bytes, unsigned x_bytes) {
+// MODE 0: dense (linear layer / 1x1 conv), 1: stride-1 taps on power-of-two Ho x Wo, 2: generic gather
+template <int MODE, bool BIAS>
+__device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int block_id, const int grid_blocks, char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) char smem[4 * WD_TILE];     // [stage][A | B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 80, wn0 = (wave & 1) * 80;
@@ -242,7 +244,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p, un
     // block order: taps fastest, then ci/co tiles, pixel split slowest - workgroups that run together (one
     // XCD-contiguous chunk) read the SAME pixel range, so the dy tile and the (tap-shifted) x rows are
     // served from that XCD's L2 instead of the fabric
-    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(block_id, grid_blocks);
+    if (lid >= p.nmain) return;              // padding block of a grouped launch
     const int tap = lid % p.taps; lid /= p.taps;
     const int tile_ci = lid % p.tiles_ci; lid /= p.tiles_ci;
     const int tile_co = lid % p.tiles_co;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p, un
     int ky = 0, kx = 0;
     if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
     const int pad = p.ksize >> 1;
-    const bool dense = p.ksize == 1 && p.stride == 1 && !p.ups;
+    const int dyy = ky - pad, dxx = kx - pad;
     const float rWo = 1.0f / (float)p.Wo, rHo = 1.0f / (float)p.Ho;
 
     const int nkt_total = (p.M + WD_BK - 1) / WD_BK;
@@ -259,50 +262,73 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p, un
     int kt_end = kt_begin + p.kt_per_split;
     if (kt_end > nkt_total) kt_end = nkt_total;
 
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, dy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
 
-    // this wave's pieces: idx = wave + 4j (< 22); idx < 11 -> dy tile, else x tile
-    int prow[6], pch[6];
+    // Wave w moves pieces w, w+4, w+8 (< 11) of BOTH operand tiles; a piece is 64 consecutive 16-byte slots
+    // of the [32][22-chunk] tile image, so a lane owns the same (pixel row, channel chunk) of its pieces for
+    // the whole contraction.  Per piece it keeps the next pixel (pm) and the byte offsets of the next dy / x
+    // fetch; slots that never hold data (spare chunks, channels past the tensor) keep an out-of-range offset
+    // and a zero step.
+    int pm[3], offA[3], offB[3], chB[3];
+    const int stepA = WD_BK * p.Cout * 2;
+    const int stepB = MODE == 0 ? WD_BK * p.ldx * 2 : WD_BK * p.Cin * 2;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int idx = wave + 4 * j;
-        const int q = (idx % WD_PIECES) * 64 + lane;
-        prow[j] = q / WD_CHUNKS;
-        pch[j] = q - prow[j] * WD_CHUNKS;
+    for (int j = 0; j < 3; ++j) {
+        const int q = (wave + 4 * j) * 64 + lane;
+        const int prow = q / WD_CHUNKS;
+        const int pch = q - prow * WD_CHUNKS;
+        const int ch = pch * 8;
+        pm[j] = kt_begin * WD_BK + prow;
+        chB[j] = ch;
+        // an out-of-range offset stays out of range under the per-tile steps (operands are < 2 GB)
+        const bool okA = pch < 20 && co0 + ch < p.Cout;
+        offA[j] = okA ? (pm[j] * p.Cout + co0 + ch) * 2 : OOB_OFF;
+        const bool okB = pch < 20 && ci0 + ch < p.Cin;
+        if (MODE == 0) offB[j] = okB ? (pm[j] * p.ldx + ci0 + ch) * 2 : OOB_OFF;
+        else if (MODE == 1) offB[j] = okB ? ((pm[j] + dyy * p.W + dxx) * p.Cin + ci0 + ch) * 2 : OOB_OFF;   // used only when the tap is in range
+        else offB[j] = okB ? 0 : OOB_OFF;
     }
+    const int npieces = wave == 3 ? 2 : 3;      // piece 11 does not exist
 
-    auto issue = [&](int kt, int stage) {
+    // pixels at or beyond m_end fetch nothing: rows past the tensor, and the tiles the pipeline requests past
+    // this workgroup's range (every iteration issues its pieces, so the vmcnt bookkeeping is uniform)
+    const int m_end = kt_end * WD_BK < p.M ? kt_end * WD_BK : p.M;
+    auto issue_piece = [&](int j, int stage) {
         char* As = smem + stage * 2 * WD_TILE;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int idx = wave + 4 * j;
-            if (idx >= 2 * WD_PIECES) continue;
-            const int m = kt * WD_BK + prow[j];
-            const int ch = pch[j] * 8;
-            int voff = OOB_OFF;
-            if (idx < WD_PIECES) {
-                if (m < p.M && pch[j] < 20 && co0 + ch < p.Cout) voff = (m * p.Cout + co0 + ch) * 2;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + idx * 1024), 16, voff, 0, 0, 0);
-            } else {
-                if (m < p.M && pch[j] < 20 && ci0 + ch < p.Cin) {
-                    if (dense) {
-                        voff = (m * p.ldx + ci0 + ch) * 2;
-                    } else {
-                        const int t = fast_div(m, p.Wo, rWo);
-                        const int ox = m - t * p.Wo;
-                        const int b = fast_div(t, p.Ho, rHo);
-                        const int oy = t - b * p.Ho;
-                        int sy = oy * p.stride - pad + ky, sx = ox * p.stride - pad + kx;
-                        bool ok = sy >= 0 && sx >= 0;
-                        if (p.ups) { sy >>= 1; sx >>= 1; }
-                        ok = ok && sy < p.H && sx < p.W;
-                        if (ok) voff = (((b * p.H + sy) * p.W + sx) * p.Cin + ci0 + ch) * 2;
-                    }
-                }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(As + WD_TILE + (idx - WD_PIECES) * 1024), 16, voff, 0, 0, 0);
-            }
+        const int idx = wave + 4 * j;
+        const int m = pm[j];
+        const bool in_m = m < m_end;
+        const int va = (in_m && offA[j] >= 0) ? offA[j] : OOB_OFF;
+        int vb;
+        if (MODE == 0) {
+            vb = (in_m && offB[j] >= 0) ? offB[j] : OOB_OFF;
+        } else if (MODE == 1) {
+            const int ox = m & (p.Wo - 1);
+            const int oy = (m >> p.lw) & (p.Ho - 1);
+            const bool ok = in_m & ((unsigned)(oy + dyy) < (unsigned)p.H) & ((unsigned)(ox + dxx) < (unsigned)p.W);
+            vb = (ok && offB[j] >= 0) ? offB[j] : OOB_OFF;
+        } else {
+            const int t = fast_div(m, p.Wo, rWo);
+            const int ox = m - t * p.Wo;
+            const int b = fast_div(t, p.Ho, rHo);
+            const int oy = t - b * p.Ho;
+            int sy = oy * p.stride + dyy, sx = ox * p.stride + dxx;
+            bool ok = in_m & (sy >= 0) & (sx >= 0);
+            if (p.ups) { sy >>= 1; sx >>= 1; }
+            ok = ok & (sy < p.H) & (sx < p.W) & (offB[j] == 0);
+            vb = ok ? (((b * p.H + sy) * p.W + sx) * p.Cin + ci0 + chB[j]) * 2 : OOB_OFF;
         }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + idx * 1024), 16, va, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(As + WD_TILE + idx * 1024), 16, vb, 0, 0, 0);
+        pm[j] = m + WD_BK;
+        offA[j] += stepA;
+        if (MODE != 2) offB[j] += stepB;
+    };
+    auto issue_tile = [&](int stage) {
+        issue_piece(0, stage);
+        issue_piece(1, stage);
+        if (npieces == 3) issue_piece(2, stage);
     };
 
     f32x4 acc[5][5];
@@ -310,47 +336,125 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p, un
     for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = p.dbias != nullptr && tile_ci == 0 && tap == 0;
-    float bsum = 0.f;
 
     const int g = lane >> 4, li = lane & 15;
     const int tr_off = (4 * g + (li >> 2)) * WG_LD + (li & 3) * 8;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned a_rd = lds_base + tr_off + wm0 * 2;
+    const unsigned b_rd = lds_base + WD_TILE + tr_off + wn0 * 2;
 
-    if (kt_begin < kt_end) issue(kt_begin, 0);
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Software pipeline over 32-pixel tiles with three LDS stages:
+    //   iteration t:  wait until tile t+1 has landed (tile t+2 may still be in flight) -> barrier ->
+    //                 MFMAs on the fragments of tile t, interleaved with the transposing LDS reads of tile t+1
+    //                 and with the DMA requests for tile t+3, which overwrite the stage of tile t (every wave
+    //                 finished reading it before the barrier)
+    // so neither the LDS reads nor the DMA issue sit between a barrier and the matrix instructions.  The dy
+    // fragment of row block i is dead after its five MFMAs and is refilled in place; the x fragments are
+    // used by every row block, so they alternate between two register sets.
+    bf16x4 alo[5], ahi[5], blo0[5], bhi0[5], blo1[5], bhi1[5];
+    auto read_a = [&](int i, unsigned a_addr) {     // i is a compile-time constant after unrolling
+        switch (i) {
+            case 0: alo[0] = lds_tr<0>(a_addr);   ahi[0] = lds_tr<16 * WG_LD>(a_addr); break;
+            case 1: alo[1] = lds_tr<32>(a_addr);  ahi[1] = lds_tr<32 + 16 * WG_LD>(a_addr); break;
+            case 2: alo[2] = lds_tr<64>(a_addr);  ahi[2] = lds_tr<64 + 16 * WG_LD>(a_addr); break;
+            case 3: alo[3] = lds_tr<96>(a_addr);  ahi[3] = lds_tr<96 + 16 * WG_LD>(a_addr); break;
+            default: alo[4] = lds_tr<128>(a_addr); ahi[4] = lds_tr<128 + 16 * WG_LD>(a_addr); break;
+        }
+    };
+    auto read_b = [&](bf16x4 (&lo)[5], bf16x4 (&hi)[5], int i, unsigned b_addr) {
+        switch (i) {
+            case 0: lo[0] = lds_tr<0>(b_addr);   hi[0] = lds_tr<16 * WG_LD>(b_addr); break;
+            case 1: lo[1] = lds_tr<32>(b_addr);  hi[1] = lds_tr<32 + 16 * WG_LD>(b_addr); break;
+            case 2: lo[2] = lds_tr<64>(b_addr);  hi[2] = lds_tr<64 + 16 * WG_LD>(b_addr); break;
+            case 3: lo[3] = lds_tr<96>(b_addr);  hi[3] = lds_tr<96 + 16 * WG_LD>(b_addr); break;
+            default: lo[4] = lds_tr<128>(b_addr); hi[4] = lds_tr<128 + 16 * WG_LD>(b_addr); break;
+        }
+    };
+    auto frag = [](const bf16x4& lo, const bf16x4& hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
+    // Bias gradient (BIAS instances: the workgroups of ci tile 0, tap 0, which see every dy row once): after the
+    // transposing read a lane holds 8 pixels of ONE channel, so four packed dot products against ones add them to
+    // a per-lane partial column sum; the two waves that share a dy row block split its five 16-channel groups.
+    float bsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16_t one = (bf16_t)1.0f;
+    const bf16x2 ones2 = {one, one};
+    const bool bias_lo = (wave & 1) == 0;
+    auto mfma_row = [&](const bf16x4 (&lo)[5], const bf16x4 (&hi)[5], int i) {
+        const bf16x8 a = frag(alo[i], ahi[i]);
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag(lo[j], hi[j]), acc[i][j], 0, 0, 0);
+        if (BIAS && ((i < 3) == bias_lo)) {
+            float t = bsum[i];
+            t = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{alo[i][0], alo[i][1]}, ones2, t, false);
+            t = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{alo[i][2], alo[i][3]}, ones2, t, false);
+            t = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{ahi[i][0], ahi[i][1]}, ones2, t, false);
+            t = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{ahi[i][2], ahi[i][3]}, ones2, t, false);
+            bsum[i] = t;
+        }
+    };
+    auto wait_tile = [&]() {        // all but this wave's youngest tile request have landed
+        if (npieces == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+    // one pipeline iteration: x fragments of the current tile in (clo, chi), the next tile's go to (nlo, nhi)
+    auto iteration = [&](const bf16x4 (&clo)[5], const bf16x4 (&chi)[5], bf16x4 (&nlo)[5], bf16x4 (&nhi)[5],
+                         int rd_stage, int wr_stage) {
+        wait_tile();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
-        const char* As = smem + cur * 2 * WD_TILE;
-        const char* Bs = As + WD_TILE;
-        bf16x8 af[5], bfr[5];
+        const unsigned a_addr = a_rd + rd_stage * 2 * WD_TILE, b_addr = b_rd + rd_stage * 2 * WD_TILE;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const char* pa = As + tr_off + (wm0 + i * 16) * 2;
-            af[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa + 16 * WG_LD));
-            af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const char* pb = Bs + tr_off + (wn0 + i * 16) * 2;
-            const bf16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pb));
-            const bf16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pb + 16 * WG_LD));
-            bfr[i] = bf16x8{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+            mfma_row(clo, chi, i);
+            read_a(i, a_addr);
+            read_b(nlo, nhi, i, b_addr);
+            if (i < 2) issue_piece(i, wr_stage);
+            else if (i == 2 && npieces == 3) issue_piece(2, wr_stage);
         }
+        lds_wait(alo, ahi);
+        lds_wait(nlo, nhi);
+    };
+
+    if (kt_begin >= kt_end) return;
+    issue_tile(0); issue_tile(1); issue_tile(2);
+    if (npieces == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        if (do_bias && tid < WG_BT) {
-            const bf16_t* col = (const bf16_t*)As + tid;
-#pragma unroll 8
-            for (int r = 0; r < WD_BK; ++r) bsum += (float)col[r * (WG_LD / 2)];
-        }
-        cur ^= 1;
+    for (int i = 0; i < 5; ++i) { read_a(i, a_rd); read_b(blo0, bhi0, i, b_rd); }
+    lds_wait(alo, ahi);
+    lds_wait(blo0, bhi0);
+
+    int st = 0;                                    // LDS stage of the tile whose fragments are in registers
+    int kt = kt_begin;
+    for (; kt + 2 < kt_end; kt += 2) {
+        const int s1 = st == 2 ? 0 : st + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        iteration(blo0, bhi0, blo1, bhi1, s1, st);
+        iteration(blo1, bhi1, blo0, bhi0, s2, s1);
+        st = s2;
     }
-    if (do_bias && tid < WG_BT && co0 + tid < p.Cout) atomicAdd(p.dbias + co0 + tid, bsum);
+    if (kt + 1 < kt_end) {
+        iteration(blo0, bhi0, blo1, bhi1, st == 2 ? 0 : st + 1, st);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) mfma_row(blo1, bhi1, i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) mfma_row(blo0, bhi0, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA write may outlive the workgroup's LDS
+
+    if (BIAS) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if ((i < 3) != bias_lo) continue;
+            float t = bsum[i];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            const int co = co0 + wm0 + i * 16 + li;
+            if (g == 0 && co < p.Cout) atomicAdd(p.dbias + co, t);
+        }
+    }
 
     const int ktot = p.taps * p.Cin;
 #pragma unroll
@@ -368,6 +472,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p, un
                 }
             }
 #endif
+}
+
+__device__ __forceinline__ void wgrad_dma_dispatch(const WgradArgs& p, const int block_id, const int grid_blocks, char* smem) {
+    const bool linear = p.stride == 1 && !p.ups;
+    const int mode = (p.ksize == 1 && linear) ? 0 : (linear && p.lw >= 0) ? 1 : 2;
+    bool bias = false;
+    if (p.dbias != nullptr) {                    // same decode as the body: tap fastest, then the ci tile
+        const int lid = xcd_remap(block_id, grid_blocks);
+        bias = lid % p.taps == 0 && (lid / p.taps) % p.tiles_ci == 0;
+    }
+    if (bias) {
+        if (mode == 0) wgrad_dma_body<0, true>(p, block_id, grid_blocks, smem);
+        else if (mode == 1) wgrad_dma_body<1, true>(p, block_id, grid_blocks, smem);
+        else wgrad_dma_body<2, true>(p, block_id, grid_blocks, smem);
+    } else {
+        if (mode == 0) wgrad_dma_body<0, false>(p, block_id, grid_blocks, smem);
+        else if (mode == 1) wgrad_dma_body<1, false>(p, block_id, grid_blocks, smem);
+        else wgrad_dma_body<2, false>(p, block_id, grid_blocks, smem);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[6 * WD_TILE];     // [stage][A | B]
+    wgrad_dma_dispatch(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Many independent weight-gradient problems in ONE launch (deferred from the backward pass): job j owns
+// blocks [first_block_j, first_block_{j+1}), padded to a multiple of 8 so the XCD-aware block order of
+// each job is preserved.  With thousands of tiles in flight no job needs an aggressive pixel split, so
+// atomic traffic drops and small layers no longer run alone on a mostly idle chip.
+struct WgradJob {
+    WgradArgs a;
+    int first_block;
+    int nblocks;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_grouped_kernel(const WgradJob* __restrict__ jobs, int njobs) {
+    __shared__ __attribute__((aligned(16))) char smem[6 * WD_TILE];
+    int lo = 0, hi = njobs - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {                           // wave-uniform binary search over the block prefix
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+    }
+    const WgradJob& j = jobs[lo];
+    WgradArgs p = j.a;
+    wgrad_dma_dispatch(p, bid - j.first_block, j.nblocks, smem);
 }
 
 // Column sums of a bf16 matrix in segments of `seg` rows: out[s][n] = sum_{m in segment s} y[m][n].
@@ -420,16 +571,34 @@ static void colsum_geometry(int M, int N, int seg, int* rows_per_block, int* chu
 
 extern "C" {
 
-static void wgrad_plan(WgradArgs& a, int B, int Cin, int Cout, int ksize, int Ho, int Wo, int target_kt) {
-    a.M = B * Ho * Wo; a.Cout = Cout; a.Cin = Cin;
+static int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// Geometry shared by the single and grouped launches; bk = pixels per k-tile of the kernel that will run.
+static void wgrad_geometry(WgradArgs& a, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int ups, int Ho, int Wo) {
+    a.M = B * Ho * Wo; a.Cout = Cout; a.Cin = Cin; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+    a.stride = stride; a.ups = ups; a.ksize = ksize; a.ldx = Cin;
     a.taps = ksize * ksize;
     a.tiles_co = (Cout + WG_BT - 1) / WG_BT;
     a.tiles_ci = (Cin + WG_BT - 1) / WG_BT;
-    const int nkt = (a.M + WG_BK - 1) / WG_BK;
-    int s = (nkt + target_kt - 1) / target_kt;
-    if (s < 1) s = 1;
-    a.kt_per_split = (nkt + s - 1) / s;
-    a.splits = (nkt + a.kt_per_split - 1) / a.kt_per_split;
+    a.lw = ilog2_exact(Wo); a.lh = ilog2_exact(Ho);
+    if (a.lw < 0 || a.lh < 0) a.lw = a.lh = -1;
+}
+static bool wgrad_dma_extents(WgradArgs& a) {
+    const bool dense = a.ksize == 1 && a.stride == 1 && !a.ups;
+    const double dy_sz = (double)a.M * a.Cout * 2.0;
+    const double x_sz = dense ? (double)a.M * a.Cin * 2.0 : (double)a.B * a.H * a.W * a.Cin * 2.0;
+    if (dy_sz >= 2.0e9 || x_sz >= 2.0e9) return false;
+    a.dy_bytes = (unsigned)dy_sz; a.x_bytes = (unsigned)x_sz;
+    return true;
+}
+static int wgrad_dma_blocks(WgradArgs& a) {
+    a.nmain = a.tiles_co * a.tiles_ci * a.taps * a.splits;
+    return a.nmain;
 }
 
 int mi355_wgrad_job_bytes(void) { return (int)sizeof(WgradJob); }
@@ -447,10 +616,18 @@ int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* d
     WgradArgs& a = j->a;
     a = WgradArgs{};
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.dw = dw; a.dbias = dbias;
-    a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ups = ups; a.ksize = ksize; a.ldx = Cin;
-    wgrad_plan(a, B, Cin, Cout, ksize, Ho, Wo, 64);
+    wgrad_geometry(a, B, H, W, Cin, Cout, ksize, stride, ups, Ho, Wo);
+    if (!wgrad_dma_extents(a)) return mi355_fail(MI355_ERR_UNSUPPORTED, "wgrad_job_fill: operand of 2 GB or more");
+    {   // pixel split: about 8192 pixels (256 k-tiles of 32) per workgroup; measured best of 64..512
+        const int nkt = (a.M + WD_BK - 1) / WD_BK;
+        static const int target = getenv("MI355_WGRAD_KT") ? atoi(getenv("MI355_WGRAD_KT")) : 256;
+        int sp = (nkt + target - 1) / target;
+        if (sp < 1) sp = 1;
+        a.kt_per_split = (nkt + sp - 1) / sp;
+        a.splits = (nkt + a.kt_per_split - 1) / a.kt_per_split;
+    }
     a.use_atomic = a.splits > 1 ? 1 : 0;
-    const int blocks = a.tiles_co * a.tiles_ci * a.taps * a.splits;
+    const int blocks = wgrad_dma_blocks(a);
     j->first_block = first_block;
     j->nblocks = (blocks + 7) & ~7;
     if (splits_out) *splits_out = a.splits;
@@ -472,20 +649,13 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
     if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "wgrad: ksize %d", ksize);
     if ((Cin & 7) || (Cout & 7)) return mi355_fail(MI355_ERR_ARG, "wgrad: channels must be multiples of 8");
     WgradArgs a = {};
-    a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.dw = dw;
-    a.M = B * Ho * Wo; a.Cout = Cout; a.Cin = Cin; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
-    a.stride = stride; a.ups = ups; a.ksize = ksize; a.ldx = Cin; a.dbias = dbias;
-    a.taps = ksize * ksize;
-    a.tiles_co = (Cout + WG_BT - 1) / WG_BT;
-    a.tiles_ci = (Cin + WG_BT - 1) / WG_BT;
+    a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.dw = dw; a.dbias = dbias;
+    wgrad_geometry(a, B, H, W, Cin, Cout, ksize, stride, ups, Ho, Wo);
     const int tiles = a.tiles_co * a.tiles_ci * a.taps;
-    // The LDS-DMA variant wins on long unsplit contractions (8192^3: 866 vs 821 TFLOP/s) but loses on the
-    // denoiser's split, im2col-addressed shapes (per-piece address arithmetic, short k-tiles), so the
-    // register-staged kernel stays the default; MI355_WGRAD_DMA=1 selects the DMA variant.
-    static const bool force_v1 = getenv("MI355_WGRAD_DMA") == nullptr;
-    const double dy_sz = (double)a.M * Cout * 2.0;
-    const double x_sz = (ksize == 1 && stride == 1 && !ups) ? (double)a.M * Cin * 2.0 : (double)B * H * W * Cin * 2.0;
-    const bool dma = !force_v1 && dy_sz < 2.0e9 && x_sz < 2.0e9;
+    // The LDS-DMA kernel is the default; operands of 2 GB or more (beyond a buffer descriptor's reach) and
+    // MI355_WGRAD_V1=1 take the register-staged kernel.
+    static const bool force_v1 = getenv("MI355_WGRAD_V1") != nullptr;
+    const bool dma = wgrad_dma_extents(a) && !force_v1;
     const int bk = dma ? WD_BK : WG_BK;
     const int nkt = (a.M + bk - 1) / bk;
     // split choice: waves of 512 co-resident workgroups, ~1 us per 64-pixel k-tile, fp32 atomics at ~1.3 TB/s
@@ -517,7 +687,7 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
         return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed");
     ProfScope prof(FAM_WGRAD, st, 2.0 * a.M * Cout * (double)a.taps * Cin);
     if (dma)
-        hipLaunchKernelGGL(wgrad_dma_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a, (unsigned)dy_sz, (unsigned)x_sz);
+        hipLaunchKernelGGL(wgrad_dma_kernel, dim3(wgrad_dma_blocks(a)), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a);
     return mi355_check_launch("wgrad_kernel");

@@ -6,6 +6,7 @@ libmi355_denoiser.so.  Activations are bf16, token-major / NHWC.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 
 import torch
@@ -105,7 +106,7 @@ class WgradQueue:
     grouped launch.  Thousands of tiles in flight keep all 256 CUs busy without aggressive pixel splits
     (less atomic traffic) and remove ~230 small launches per step.  Destinations must be pre-zeroed."""
 
-    def __init__(self, device, flush_blocks=4096, max_jobs=512, ring=64):
+    def __init__(self, device, flush_blocks=int(os.environ.get("MI355_WGRAD_FLUSH", "4096")), max_jobs=512, ring=64):
         self.device = device
         self.jb = int(lib.mi355_wgrad_job_bytes())
         self.max_jobs, self.flush_blocks = max_jobs, flush_blocks
