@@ -104,10 +104,18 @@ def wgrad(dy, x, cin, cout, ksize=1, stride=1, ups=False, geom=None, out=None, a
 class WgradQueue:
     """Deferred weight gradients: backward pushes (dy, x, destination) jobs, `flush()` runs them as ONE
     grouped launch.  Thousands of tiles in flight keep all 256 CUs busy without aggressive pixel splits
-    (less atomic traffic) and remove ~230 small launches per step.  Destinations must be pre-zeroed."""
+    (less atomic traffic) and remove ~230 small launches per step.  Destinations must be pre-zeroed.
 
-    def __init__(self, device, flush_blocks=int(os.environ.get("MI355_WGRAD_FLUSH", "4096")), max_jobs=512, ring=64):
+    With `side_stream=True` the grouped launches run on a second stream, concurrently with the rest of the
+    backward pass (whose small normalisation / projection kernels leave most CUs idle); `join()` makes the
+    current stream wait for them.  Operands stay referenced until `join()`, so the allocator cannot hand their
+    memory to a later kernel of the main stream while a grouped launch still reads it."""
+
+    def __init__(self, device, flush_blocks=int(os.environ.get("MI355_WGRAD_FLUSH", "4096")), max_jobs=512, ring=64,
+                 side_stream=False):
         self.device = device
+        self.side = torch.cuda.Stream(device) if side_stream else None
+        self._inflight = []
         self.jb = int(lib.mi355_wgrad_job_bytes())
         self.max_jobs, self.flush_blocks = max_jobs, flush_blocks
         self._ring = [torch.empty(max_jobs * self.jb, dtype=torch.uint8).pin_memory() for _ in range(ring)]
@@ -140,9 +148,19 @@ class WgradQueue:
         if self._n == 0:
             return
         nbytes = self._n * self.jb
-        table = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        table.copy_(self._host[:nbytes], non_blocking=True)
-        check(lib.mi355_wgrad_grouped(table.data_ptr(), self._n, self._blocks, self._flops, _stream()), "wgrad_grouped")
+
+        def launch():
+            table = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            table.copy_(self._host[:nbytes], non_blocking=True)
+            check(lib.mi355_wgrad_grouped(table.data_ptr(), self._n, self._blocks, self._flops, _stream()), "wgrad_grouped")
+            return table
+
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())      # every queued dy / x has been produced
+            with torch.cuda.stream(self.side):
+                self._inflight.append((launch(), self._refs))
+        else:
+            launch()
         for cb in self._cbs:
             cb()
         if torch.cuda.is_current_stream_capturing():
@@ -159,6 +177,13 @@ class WgradQueue:
         self._host = self._ring[self._ri]
         self._n, self._blocks, self._flops = 0, 0, 0.0
         self._refs, self._cbs = [], []
+
+    def join(self):
+        """Flush, then make the current stream wait for every grouped launch issued so far."""
+        self.flush()
+        if self.side is not None and self._inflight:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._inflight = []
 
 
 _WGRAD_QUEUE = None
