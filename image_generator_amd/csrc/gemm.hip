@@ -52,7 +52,7 @@ struct GemmArgs {
 enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2 };
 
 // Shared tail of both GEMM kernels: split-K slab store, or the LDS-staged vectorised epilogue.
-template <int BN, int TM, int TN>
+template <int BN, int TM, int TN, int NTHREADS = 256>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], char* smem, int m0, int n0,
                                               int split, int wm0, int wn0, int wave, int tid, int fr, int fq) {
     constexpr int EP_LD = BN + 4;
@@ -76,18 +76,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     float* ep = (float*)smem;
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
-        if ((wave >> 1) == h) {
+        const int wrow = wm0 - h * 64;              // this wave's first row inside the 64-row half, if it is in it
+        if (wrow >= 0 && wrow < 64) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        ep[(i * 16 + fq * 4 + r) * EP_LD + wn0 + j * 16 + fr] = acc[i][j][r];
+                        ep[(wrow + i * 16 + fq * 4 + r) * EP_LD + wn0 + j * 16 + fr] = acc[i][j][r];
         }
         __syncthreads();
         constexpr int NC = BN / 8;
-        for (int idx = tid; idx < 64 * NC; idx += 256) {
+        for (int idx = tid; idx < 64 * NC; idx += NTHREADS) {
             const int row = idx / NC, c8 = idx - row * NC;
             const int m = m0 + h * 64 + row, n = n0 + c8 * 8;
             if (m >= p.M || n >= p.N) continue;
@@ -304,13 +305,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr int OOB_OFF = (int)0x80000000;
 
-template <int BN, int AMODE>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
+// NW = 4: 2x2 waves of 64 x BN/2, two workgroups per CU.  NW = 8: 4x2 waves of 32 x BN/2 on the same tile, for
+// grids of at most one workgroup per CU: a lone 4-wave workgroup has one wave per SIMD, whose DMA issue, LDS
+// reads and MFMAs serialise; eight waves give every SIMD a second wave to overlap them with.
+template <int BN, int AMODE, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the body uses device-only buffer-resource builtins
     constexpr int BM = 128, BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / (NW / 2), WN = BN / 2;
     constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr int A_P = BM / 32, B_P = BN / 32;          // 1 KiB pieces per wave
+    constexpr int A_P = BM / 8 / NW;                     // 1 KiB pieces (8 rows x 128 B) per wave
+    constexpr int B_PIECES = BN / 8, B_P = (B_PIECES + NW - 1) / NW;
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p, unsi
     const int pad = p.g.ksize >> 1;
 #pragma unroll
     for (int j = 0; j < A_P; ++j) {
-        const int m = m0 + (wave + 4 * j) * 8 + sr;
+        const int m = m0 + (wave + NW * j) * 8 + sr;
         const bool ok = m < p.M;
         if constexpr (AMODE == AMODE_DENSE) {
             a_voff[j] = ok ? (m * p.lda + kc * 8) * 2 : OOB_OFF;
@@ -358,9 +363,10 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p, unsi
     int b_voff[B_P];
 #pragma unroll
     for (int j = 0; j < B_P; ++j) {
-        const int n = n0 + (wave + 4 * j) * 8 + sr;
+        const int n = n0 + (wave + NW * j) * 8 + sr;
         b_voff[j] = n < p.N ? (n * p.ldb + kc * 8) * 2 : OOB_OFF;
     }
+    const int nbp = (B_PIECES - wave + NW - 1) / NW;     // B pieces of this wave (uneven when NW does not divide them)
 
     auto issue = [&](int kt, int stage) {
         char* As = smem + stage * STAGE;
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p, unsi
             const int soff = kt * (BK * 2);
 #pragma unroll
             for (int j = 0; j < A_P; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + 4 * j) * 1024), 16, a_voff[j], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + NW * j) * 1024), 16, a_voff[j], soff, 0, 0);
         } else {
             const int kk = kt * BK;
             const int tap = kk / p.g.C;
@@ -388,13 +394,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p, unsi
                 }
                 ok = ok && sy < p.g.H && sx < p.g.W;
                 const int voff = ok ? ((a_voff[j] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + 4 * j) * 1024), 16, voff, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + NW * j) * 1024), 16, voff, soff, 0, 0);
             }
         }
         const int soffb = kt * (BK * 2);
 #pragma unroll
         for (int j = 0; j < B_P; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(Bs + (wave + 4 * j) * 1024), 16, b_voff[j], soffb, 0, 0);
+            if (B_PIECES % NW == 0 || j < nbp)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(Bs + (wave + NW * j) * 1024), 16, b_voff[j], soffb, 0, 0);
     };
 
     f32x4 acc[TM][TN];
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p, unsi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BN, TM, TN>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+    gemm_epilogue<BN, TM, TN, NW * 64>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
 #endif
 }
 
@@ -516,6 +523,17 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
         attr_set = true;
     }
     const int grid = a.tiles_m * a.tiles_n * a.splitk;
+    // measured on the denoiser step: 8 waves win up to two workgroups per CU, 4 waves beyond
+    static const int nw8_max = getenv("MI355_GEMM_NW8") ? atoi(getenv("MI355_GEMM_NW8")) : 512;
+    if (grid <= nw8_max) {
+        static bool attr8_set = false;
+        if (!attr8_set) {
+            hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr8_set = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8>), dim3(grid), dim3(512), smem, s, a, a_bytes, b_bytes);
+        return mi355_check_launch("gemm_dma_kernel<8 waves>");
+    }
     hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE>), dim3(grid), dim3(256), smem, s, a, a_bytes, b_bytes);
     return mi355_check_launch("gemm_dma_kernel");
 }
