@@ -61,14 +61,29 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // out[s][n] = sum_r partial[s][r][n]; launch with grid (ceil(N/64), nseg), 256 threads (64 columns x 4 row phases).
 // (static: every translation unit that launches it carries its own copy; no relocatable device code needed)
 static __global__ void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int R, int N) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6, s = blockIdx.y;
-    float acc = 0.f;
-    if (col < N)
-        for (int r = ph; r < R; r += 4) acc += partial[((size_t)s * R + r) * N + col];
-    red[ph][threadIdx.x & 63] = acc;
+    // 256 threads = 16 groups of 4 columns (one 16-byte load each) x 16 row phases; N must be a multiple of 4
+    __shared__ f32x4 red[16][16];
+    const int cg = threadIdx.x & 15, ph = threadIdx.x >> 4, s = blockIdx.y;
+    const int col = blockIdx.x * 64 + cg * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        const float* src = partial + (size_t)s * R * N + col;
+        int r = ph;
+        for (; r + 48 < R; r += 64) {
+            const f32x4 a = *(const f32x4*)(src + (size_t)r * N), b = *(const f32x4*)(src + (size_t)(r + 16) * N);
+            const f32x4 c = *(const f32x4*)(src + (size_t)(r + 32) * N), d = *(const f32x4*)(src + (size_t)(r + 48) * N);
+            acc += (a + b) + (c + d);
+        }
+        for (; r < R; r += 16) acc += *(const f32x4*)(src + (size_t)r * N);
+    }
+    red[ph][cg] = acc;
     __syncthreads();
-    if (ph == 0 && col < N) out[(size_t)s * N + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (ph == 0 && col < N) {
+        f32x4 t = red[0][cg];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += red[q][cg];
+        *(f32x4*)(out + (size_t)s * N + col) = t;
+    }
 }
 
 // Blocks that share an XCD (ids congruent mod 8) get one contiguous chunk of the logical grid.

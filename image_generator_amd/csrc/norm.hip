@@ -277,41 +277,53 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// dx per row; dgamma/dbeta partials kept in registers across the rows a wave visits, combined by atomics.
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     bf16_t* __restrict__ dx, float* __restrict__ partial,
-                                                     int M, int C) {
+// dx per row; dgamma/dbeta partials kept in registers across the rows a wave visits, combined per block with
+// LDS atomics, one partial row per block.  NCH = 8-channel chunks per lane (C <= 512 * NCH).  1024-thread
+// blocks (512 for the wide rows, whose per-lane state needs more registers): 8-16 waves per CU keep enough
+// rows in flight to cover the load -> reduce -> store chain of each row.
+template <int NCH>
+__global__ __launch_bounds__(NCH <= 2 ? 1024 : 512) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      bf16_t* __restrict__ dx, float* __restrict__ partial,
+                                                      int M, int C) {
+    extern __shared__ float lred[];      // [2][C] block sums (dgamma, dbeta), then [C] gamma
+    float* lgam = lred + 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lred[i] = 0.f;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) lgam[i] = gamma[i];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nc = C >> 3;
-    float pg[LN_MAXCH][8], pb[LN_MAXCH][8], ga[LN_MAXCH][8];
+    float pg[NCH][8], pb[NCH][8];
 #pragma unroll
-    for (int k = 0; k < LN_MAXCH; ++k)
+    for (int k = 0; k < NCH; ++k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            pg[k][e] = 0.f; pb[k][e] = 0.f;
-            const int c8 = lane + 64 * k;
-            ga[k][e] = c8 < nc ? gamma[c8 * 8 + e] : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) { pg[k][e] = 0.f; pb[k][e] = 0.f; }
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += gridDim.x * wpb) {
         const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
-        float xh[LN_MAXCH][8], dg[LN_MAXCH][8];
+        bf16x8 xv[NCH], dv[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXCH; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int c8 = lane + 64 * k;
             if (c8 < nc) {
-                const bf16x8 xv = *(const bf16x8*)(x + (size_t)row * C + c8 * 8);
-                const bf16x8 dv = *(const bf16x8*)(dy + (size_t)row * C + c8 * 8);
+                xv[k] = *(const bf16x8*)(x + (size_t)row * C + c8 * 8);
+                dv[k] = *(const bf16x8*)(dy + (size_t)row * C + c8 * 8);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c8 = lane + 64 * k;
+            if (c8 < nc) {
+                const f32x4 g0 = *(const f32x4*)(lgam + c8 * 8), g1 = *(const f32x4*)(lgam + c8 * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float d = (float)dv[e];
-                    xh[k][e] = ((float)xv[e] - mean) * rstd;
-                    dg[k][e] = d * ga[k][e];
-                    s1 += dg[k][e];
-                    s2 += dg[k][e] * xh[k][e];
-                    pg[k][e] += d * xh[k][e];
+                    const float d = (float)dv[k][e];
+                    const float xh = ((float)xv[k][e] - mean) * rstd;
+                    const float dg = d * (e < 4 ? g0[e] : g1[e - 4]);
+                    s1 += dg;
+                    s2 += dg * xh;
+                    pg[k][e] += d * xh;
                     pb[k][e] += d;
                 }
             }
@@ -319,36 +331,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         s1 = wave_sum(s1) / C;
         s2 = wave_sum(s2) / C;
 #pragma unroll
-        for (int k = 0; k < LN_MAXCH; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int c8 = lane + 64 * k;
             if (c8 < nc) {
+                const f32x4 g0 = *(const f32x4*)(lgam + c8 * 8), g1 = *(const f32x4*)(lgam + c8 * 8 + 4);
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(rstd * (dg[k][e] - s1 - xh[k][e] * s2));
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)xv[k][e] - mean) * rstd;
+                    const float dg = (float)dv[k][e] * (e < 4 ? g0[e] : g1[e - 4]);
+                    o[e] = (bf16_t)(rstd * (dg - s1 - xh * s2));
+                }
                 *(bf16x8*)(dx + (size_t)row * C + c8 * 8) = o;
             }
         }
     }
-    // combine the block's waves through LDS, then one partial row per block: partial[block][2][C]
-    extern __shared__ float lred[];      // [wpb][2][C]
-    const int w = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < LN_MAXCH; ++k) {
+    for (int k = 0; k < NCH; ++k) {
         const int c8 = lane + 64 * k;
         if (c8 < nc) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                lred[((size_t)w * 2) * C + c8 * 8 + e] = pg[k][e];
-                lred[((size_t)w * 2 + 1) * C + c8 * 8 + e] = pb[k][e];
+                atomicAdd(lred + c8 * 8 + e, pg[k][e]);
+                atomicAdd(lred + C + c8 * 8 + e, pb[k][e]);
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-        float sacc = 0.f;
-        for (int q = 0; q < wpb; ++q) sacc += lred[(size_t)q * 2 * C + i];
-        partial[(size_t)blockIdx.x * 2 * C + i] = sacc;
-    }
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) partial[(size_t)blockIdx.x * 2 * C + i] = lred[i];
 }
 
 static int gn_geometry(int HW, int C, int G, int* threads, int* rpar, int* rows_per_block, int* strips) {
@@ -427,7 +437,7 @@ int mi355_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 }
 
 static int ln_bwd_grid(int M) {
-    int grid = (M + 3) / 4;
+    int grid = (M + 7) / 8;              // 8 or 16 waves per block, one row per wave at a time
     return grid > 256 ? 256 : grid;
 }
 long long mi355_layernorm_bwd_scratch_floats(int M, int C) { return (long long)ln_bwd_grid(M) * 2 * C; }
@@ -442,8 +452,14 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
     hipStream_t st = (hipStream_t)stream;
     const int grid = ln_bwd_grid(M);
     ProfScope prof(FAM_NORM, st, (double)M * C * 2 * 3);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * 2 * C * sizeof(float), st, (const bf16_t*)x,
-                       (const bf16_t*)dy, stats, gamma, (bf16_t*)dx, scratch, M, C);
+    const size_t sh = (size_t)3 * C * sizeof(float);
+#define LN_BWD(NCH) hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(NCH <= 2 ? 1024 : 512), sh, st, (const bf16_t*)x, \
+                                       (const bf16_t*)dy, stats, gamma, (bf16_t*)dx, scratch, M, C)
+    if (C <= 512) LN_BWD(1);
+    else if (C <= 1024) LN_BWD(2);
+    else if (C <= 1536) LN_BWD(3);
+    else LN_BWD(4);
+#undef LN_BWD
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, scratch, dgamma_dbeta, grid, 2 * C);
     return mi355_check_launch("layernorm_bwd");
 }
