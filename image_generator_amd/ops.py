@@ -247,9 +247,10 @@ class WeightPack:
     w16_t : data-gradient operand: [K][N] for linear layers, [Cin][k][k][Cout] tap-flipped for convs.
     """
     __slots__ = ("w16", "w16_t", "n", "k", "ksize", "cin", "cout", "cin_pad", "cout_pad", "bias_pad", "grad_out",
-                 "bias_grad_out", "on_grad_ready")
+                 "bias_grad_out", "on_grad_ready", "bias_parts")
 
     def __init__(self):
+        self.bias_parts = 0       # number of trailing bias parameters in LinearFn's `weights` (fused projections)
         self.w16 = self.w16_t = None
         self.bias_pad = None      # fp32 bias padded to cout_pad (convolutions whose Cout is not a multiple of 8)
         self.grad_out = None      # optional fp32 [N][K] view the weight gradient is written into directly
@@ -258,7 +259,9 @@ class WeightPack:
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T (+ b) (+ residual); weights may be several row-stacked parameters (fused projections)."""
+    """y = x W^T (+ b) (+ residual); weights may be several row-stacked parameters (fused projections).
+    With `pack.bias_parts = n` the last n entries of `weights` are the bias parameters whose concatenation
+    `bias` is (a view of the flat storage), and each receives its slice of the bias gradient."""
 
     @staticmethod
     def forward(ctx, x, pack, bias, residual, out_fp32, *weights):
@@ -270,6 +273,10 @@ class LinearFn(torch.autograd.Function):
         ctx.xshape = x.shape
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
+        nb = pack.bias_parts
+        ctx.bshapes = [b.shape for b in weights[len(weights) - nb:]] if nb else []
+        ctx.breq = [b.requires_grad for b in weights[len(weights) - nb:]] if nb else []
+        weights = weights[:len(weights) - nb] if nb else weights
         ctx.wshapes = [w.shape for w in weights]
         ctx.wreq = [w.requires_grad for w in weights]
         return y.view(*x.shape[:-1], y.shape[-1])
@@ -285,7 +292,7 @@ class LinearFn(torch.autograd.Function):
         dx = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = gemm(dy2, pack.w16_t.view(pack.k, pack.n)).view(ctx.xshape)
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        want_db = ctx.has_bias and (ctx.needs_input_grad[2] or any(ctx.breq))
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2.view(dy.shape)
         dws = [None] * len(ctx.wshapes)
@@ -313,7 +320,35 @@ class LinearFn(torch.autograd.Function):
                     r0 += shp[0]
         elif want_db:
             db = colsum(dy2)[0]
-        return (dx, None, db, dres, None, *dws)
+        dbs = [None] * len(ctx.bshapes)
+        if ctx.bshapes and db is not None:
+            r0 = 0
+            for i, shp in enumerate(ctx.bshapes):
+                if ctx.breq[i]:
+                    dbs[i] = db[r0:r0 + shp[0]]
+                r0 += shp[0]
+            db = None
+        return (dx, None, db, dres, None, *dws, *dbs)
+
+
+class SplitColsFn(torch.autograd.Function):
+    """Column slices of a [B, N] matrix as views (row stride N); backward concatenates the slice gradients."""
+
+    @staticmethod
+    def forward(ctx, y, sizes):
+        ctx.sizes = sizes
+        ctx.meta = (y.shape[0], y.dtype, y.device)
+        outs, c0 = [], 0
+        for n in sizes:
+            outs.append(y[:, c0:c0 + n])
+            c0 += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, dtype, dev = ctx.meta
+        parts = [g if g is not None else torch.zeros((B, n), dtype=dtype, device=dev) for g, n in zip(grads, ctx.sizes)]
+        return torch.cat(parts, dim=1), None
 
 
 class ConvFn(torch.autograd.Function):

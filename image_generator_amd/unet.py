@@ -28,7 +28,7 @@ import torch.nn as nn
 from ._lib import lib, check
 from . import ops
 from .ops import (BF16, F32, AttentionFn, ConvFn, GegluFn, GroupNormFn, LayerNormFn, LinearFn, SiluF32ToBf16Fn,
-                  ToNCHWFn, ToNHWCFn, WeightPack, _stream)
+                  SplitColsFn, ToNCHWFn, ToNHWCFn, WeightPack, _stream)
 
 
 @dataclass
@@ -155,10 +155,12 @@ class ResnetBlock(nn.Module):
         self.norm2 = HipGroupNorm(groups, cout, eps)
         self.conv2 = HipConv2d(cout, cout, 3)
         self.conv_shortcut = HipConv2d(cin, cout, 1) if cin != cout else None
+        self._tproj = None          # this block's slice of the model-wide fused time-embedding projection
 
     def forward(self, x, temb_act):
         h = self.norm1(x, silu=True)
-        h = self.conv1(h, rowbias=self.time_emb_proj(temb_act, out_fp32=True))
+        rb = self._tproj if self._tproj is not None else self.time_emb_proj(temb_act, out_fp32=True)
+        h = self.conv1(h, rowbias=rb)
         h = self.norm2(h, silu=True)
         res = x if self.conv_shortcut is None else self.conv_shortcut(x)
         return self.conv2(h, residual=res)
@@ -388,8 +390,14 @@ class UNet2DConditionModel(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("UNet2DConditionModel: parameters must live on the HIP device (no CPU path)")
         wid = self._gemm_weight_ids()
-        big = [p for p in params if id(p) in wid]
-        small = [p for p in params if id(p) not in wid]
+        # the time-embedding projections of all residual blocks read the same input: their weights (and their
+        # biases) are laid out back to back so that ONE GEMM computes all of them
+        self._temb_layers = [m.time_emb_proj for m in self.modules()
+                             if isinstance(m, ResnetBlock) and isinstance(m.time_emb_proj, HipLinear)]
+        tw = {id(l.weight) for l in self._temb_layers}
+        tb = {id(l.bias) for l in self._temb_layers}
+        big = [l.weight for l in self._temb_layers] + [p for p in params if id(p) in wid and id(p) not in tw]
+        small = [l.bias for l in self._temb_layers] + [p for p in params if id(p) not in wid and id(p) not in tb]
         offs, off = {}, 0
         for p in big + small:
             offs[id(p)] = off
@@ -442,10 +450,25 @@ class UNet2DConditionModel(nn.Module):
                 pk.w16 = self._flat16[o0:o0 + pk.n * pk.k].view(pk.n, pk.k)
                 pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
                 self._packs.append(("fused", m, pk, o0))
+        self._temb_pack = None
+        tl = self._temb_layers
+        if len(tl) > 1 and all(l.weight.numel() % 8 == 0 and l.bias.numel() % 8 == 0 for l in tl):
+            pk = self._temb_pack = WeightPack()
+            pk.n, pk.k = sum(l.out_features for l in tl), tl[0].in_features
+            o0, b0 = offs[id(tl[0].weight)], offs[id(tl[0].bias)]
+            pk.w16 = self._flat16[o0:o0 + pk.n * pk.k].view(pk.n, pk.k)
+            pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
+            pk.bias_parts = len(tl)
+            self._temb_bias = flat[b0:b0 + pk.n]
+            self._temb_offs = (o0, b0)
+            self._temb_sizes = tuple(l.out_features for l in tl)
+            members = {id(l) for l in tl}          # their own packs are never used: no per-layer transposes
+            self._packs = [e for e in self._packs if not (e[0] == "linear" and id(e[1]) in members)]
+            self._packs.append(("temb", None, pk, o0))
         # one job table for every per-step weight transpose: (src, dst, R, C, T, first tile)
         jobs, first = [], 0
         for kind, m, pk, o in self._packs:
-            if kind in ("linear", "fused"):
+            if kind in ("linear", "fused", "temb"):
                 R, C, T = pk.n, pk.k, 1
             else:
                 R, C, T = pk.cout_pad, pk.cin_pad, pk.ksize * pk.ksize
@@ -512,14 +535,18 @@ class UNet2DConditionModel(nn.Module):
                 pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
                 for w in ([m.to_k, m.to_v] if m.is_cross else [m.to_q, m.to_k, m.to_v]):
                     fused_members.add(id(w))
+            elif kind == "temb":
+                pk.bias_grad_out = g[self._temb_offs[1]:self._temb_offs[1] + pk.n]
+                for l in self._temb_layers:
+                    fused_members.add(id(l))
         self._grad_packs = []          # (offset, numel, pack) of every layer whose backward writes into `g`
         for kind, m, pk, o in self._packs:
             if kind == "conv" and m.padded:
                 continue
             pk.grad_out = g[o:o + pk.n * pk.k].view(pk.n, pk.k)
-            if kind == "fused" or id(m) not in fused_members:
+            if kind in ("fused", "temb") or id(m) not in fused_members:
                 self._grad_packs.append((o, pk.n * pk.k, pk))
-            if kind != "fused" and m.bias is not None:
+            if kind not in ("fused", "temb") and m.bias is not None:
                 ob = self._offs[id(m.bias)]
                 pk.bias_grad_out = g[ob:ob + m.bias.numel()]
         for m in self.modules():
@@ -553,6 +580,13 @@ class UNet2DConditionModel(nn.Module):
         t_emb = ops.timestep_embedding(t, cfg.block_out_channels[0])
         emb = self.time_embedding(t_emb)                 # [B, 4*C0] fp32
         temb_act = SiluF32ToBf16Fn.apply(emb)            # shared by every residual block
+        resnets = [m for m in self.modules() if isinstance(m, ResnetBlock)] if self._temb_pack is not None else []
+        if resnets:
+            tl = self._temb_layers
+            tproj = LinearFn.apply(temb_act, self._temb_pack, self._temb_bias, None, True,
+                                   *[l.weight for l in tl], *[l.bias for l in tl])
+            for r, sl in zip(resnets, SplitColsFn.apply(tproj, self._temb_sizes)):
+                r._tproj = sl
         ctx = encoder_hidden_states
         if ctx.dtype != BF16:
             ctx = ctx.to(BF16)
@@ -566,6 +600,8 @@ class UNet2DConditionModel(nn.Module):
         x = self.mid_block(x, temb_act, ctx)
         for blk in self.up_blocks:
             x = blk(x, skips, temb_act, ctx)
+        for r in resnets:
+            r._tproj = None
         x = self.conv_norm_out(x, silu=True)
         x = self.conv_out(x, out_fp32=True)
         return UNetOutput(ToNCHWFn.apply(x, cfg.out_channels))
