@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// dx per row; dgamma/dbeta partials kept in registers across the rows a wave visits, combined per block with
-// LDS atomics, one partial row per block.  NCH = 8-channel chunks per lane (C <= 512 * NCH).  1024-thread
+// dx per row; dgamma/dbeta partials kept in registers across the rows a wave visits, combined per block
+// through LDS, one partial row per block.  NCH = 8-channel chunks per lane (C <= 512 * NCH).  1024-thread
 // blocks (512 for the wide rows, whose per-lane state needs more registers): 8-16 waves per CU keep enough
 // rows in flight to cover the load -> reduce -> store chain of each row.
 template <int NCH>
@@ -286,13 +286,12 @@ __global__ __launch_bounds__(NCH <= 2 ? 1024 : 512) void ln_bwd_kernel(const bf1
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       bf16_t* __restrict__ dx, float* __restrict__ partial,
                                                       int M, int C) {
-    extern __shared__ float lred[];      // [2][C] block sums (dgamma, dbeta), then [C] gamma
-    float* lgam = lred + 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lred[i] = 0.f;
-    for (int i = threadIdx.x; i < C; i += blockDim.x) lgam[i] = gamma[i];
-    __syncthreads();
+    extern __shared__ float lred[];      // [waves][2][C] per-wave sums (dgamma, dbeta), then [C] gamma
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
+    float* lgam = lred + (size_t)wpb * 2 * C;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) lgam[i] = gamma[i];
+    __syncthreads();
     const int nc = C >> 3;
     float pg[NCH][8], pb[NCH][8];
 #pragma unroll
@@ -346,19 +345,23 @@ __global__ __launch_bounds__(NCH <= 2 ? 1024 : 512) void ln_bwd_kernel(const bf1
             }
         }
     }
+    float* mine = lred + (size_t)(threadIdx.x >> 6) * 2 * C;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int c8 = lane + 64 * k;
         if (c8 < nc) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                atomicAdd(lred + c8 * 8 + e, pg[k][e]);
-                atomicAdd(lred + C + c8 * 8 + e, pb[k][e]);
-            }
+            *(f32x4*)(mine + c8 * 8) = f32x4{pg[k][0], pg[k][1], pg[k][2], pg[k][3]};
+            *(f32x4*)(mine + c8 * 8 + 4) = f32x4{pg[k][4], pg[k][5], pg[k][6], pg[k][7]};
+            *(f32x4*)(mine + C + c8 * 8) = f32x4{pb[k][0], pb[k][1], pb[k][2], pb[k][3]};
+            *(f32x4*)(mine + C + c8 * 8 + 4) = f32x4{pb[k][4], pb[k][5], pb[k][6], pb[k][7]};
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) partial[(size_t)blockIdx.x * 2 * C + i] = lred[i];
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float sacc = 0.f;
+        for (int q = 0; q < wpb; ++q) sacc += lred[(size_t)q * 2 * C + i];
+        partial[(size_t)blockIdx.x * 2 * C + i] = sacc;
+    }
 }
 
 static int gn_geometry(int HW, int C, int G, int* threads, int* rpar, int* rows_per_block, int* strips) {
@@ -452,9 +455,19 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
     hipStream_t st = (hipStream_t)stream;
     const int grid = ln_bwd_grid(M);
     ProfScope prof(FAM_NORM, st, (double)M * C * 2 * 3);
-    const size_t sh = (size_t)3 * C * sizeof(float);
-#define LN_BWD(NCH) hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(NCH <= 2 ? 1024 : 512), sh, st, (const bf16_t*)x, \
-                                       (const bf16_t*)dy, stats, gamma, (bf16_t*)dx, scratch, M, C)
+#define LN_BWD(NCH)                                                                                            \
+    do {                                                                                                       \
+        constexpr int threads = NCH <= 2 ? 1024 : 512;                                                         \
+        const size_t sh = ((size_t)(threads / 64) * 2 + 1) * C * sizeof(float);                                \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            hipFuncSetAttribute((const void*)ln_bwd_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)(((size_t)(threads / 64) * 2 + 1) * 512 * NCH * sizeof(float)));          \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(threads), sh, st, (const bf16_t*)x,            \
+                           (const bf16_t*)dy, stats, gamma, (bf16_t*)dx, scratch, M, C);                       \
+    } while (0)
     if (C <= 512) LN_BWD(1);
     else if (C <= 1024) LN_BWD(2);
     else if (C <= 1536) LN_BWD(3);
