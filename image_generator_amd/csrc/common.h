@@ -60,8 +60,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // out[s][n] = sum_r partial[s][r][n]; launch with grid (ceil(N/64), nseg), 256 threads (64 columns x 4 row phases).
 // (static: every translation unit that launches it carries its own copy; no relocatable device code needed)
-static __global__ void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int R, int N) {
-    // 256 threads = 16 groups of 4 columns (one 16-byte load each) x 16 row phases; N must be a multiple of 4
+// out[s][col] = sum over r < R of partial[s][r][col].  With out_hi != nullptr, columns >= split are written to
+// out_hi[col - split] instead (two destinations from one planar [R][2][C] partial buffer; single segment).
+static __global__ void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int R, int N,
+                                          float* __restrict__ out_hi = nullptr, int split = 0) {
+    // 256 threads = 16 groups of 4 columns (one 16-byte load each) x 16 row phases; N (and split) multiples of 4
     __shared__ f32x4 red[16][16];
     const int cg = threadIdx.x & 15, ph = threadIdx.x >> 4, s = blockIdx.y;
     const int col = blockIdx.x * 64 + cg * 4;
@@ -82,7 +85,8 @@ static __global__ void reduce_rows_kernel(const float* __restrict__ partial, flo
         f32x4 t = red[0][cg];
 #pragma unroll
         for (int q = 1; q < 16; ++q) t += red[q][cg];
-        *(f32x4*)(out + (size_t)s * N + col) = t;
+        if (out_hi != nullptr && col >= split) *(f32x4*)(out_hi + col - split) = t;
+        else *(f32x4*)(out + (size_t)s * N + col) = t;
     }
 }
 

@@ -8,7 +8,7 @@
 //   forward :  gn_partial<0> (per (b, pixel strip): sum x, sum x^2 per group)
 //              ->  gn_apply  (prologue: strips -> mean, rstd per group;  y = silu?(x*scale + shift))
 //   backward:  gn_partial<1> (per (b, strip): sum dz, sum dz*xhat per channel, and gamma-weighted per group)
-//              ->  gn_bwd_apply (prologue: strips -> group means;  dx)   +   gn_param_grads (dgamma, dbeta)
+//              ->  gn_bwd_apply (prologue: strips -> group means;  dx)   +   reduce_rows (dgamma, dbeta)
 // No atomics and no stand-alone finalize kernels: the few hundred partial sums a block needs are re-reduced
 // in its prologue, which is cheaper than a dependent launch.
 #include "common.h"
@@ -22,7 +22,7 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 // MODE 0: acc0 += x, acc1 += x^2.   MODE 1: dz = dy * act'(z); acc0 += dz, acc1 += dz * xhat.
 // grid = (strips, B); blockDim.x = nc * rows_par (nc = C/8).
 // gpart [B][strips][G][2]: per-group sums of this strip (MODE 1: weighted by gamma).
-// cpart [B][strips][C][2]: per-channel sums (MODE 1 only; feeds dgamma / dbeta).
+// cpart [B][strips][2][C]: per-channel sums (MODE 1 only; feeds dbeta / dgamma).
 template <int MODE>
 __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                   const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -48,13 +48,12 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
     }
     float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const size_t base = (size_t)b * HW * C + c8 * 8;
-    for (int r = r_begin + rp; r < r_end; r += rpar) {
-        const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)r * C);
+    // four rows in flight per thread: the loads of a row are otherwise exposed in full on every iteration
+    auto accumulate = [&](const bf16x8& xv, const bf16x8& dv) {
         if (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float v = (float)xv[e]; a0[e] += v; a1[e] += v * v; }
         } else {
-            const bf16x8 dv = *(const bf16x8*)(dy + base + (size_t)r * C);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xh = ((float)xv[e] - mu[e]) * rs[e];
@@ -63,6 +62,23 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
                 a0[e] += dz; a1[e] += dz * xh;
             }
         }
+    };
+    int r = r_begin + rp;
+    for (; r + 3 * rpar < r_end; r += 4 * rpar) {
+        bf16x8 xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = *(const bf16x8*)(x + base + (size_t)(r + u * rpar) * C);
+            if (MODE == 1) dv[u] = *(const bf16x8*)(dy + base + (size_t)(r + u * rpar) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) accumulate(xv[u], dv[u]);
+    }
+    for (; r < r_end; r += rpar) {
+        const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)r * C);
+        bf16x8 dv = xv;
+        if (MODE == 1) dv = *(const bf16x8*)(dy + base + (size_t)r * C);
+        accumulate(xv, dv);
     }
     // combine the row phases of this block through LDS
     extern __shared__ float red[];   // [rpar][nc][16]
@@ -78,10 +94,11 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
             for (int e = 0; e < 8; ++e) { a0[e] += o[e]; a1[e] += o[8 + e]; }
         }
         if (MODE == 1) {
-            float* dst = cpart + (slot * C + c8 * 8) * 2;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2)
-                *(f32x4*)(dst + 2 * e) = f32x4{a0[e], a1[e], a0[e + 1], a1[e + 1]};
+            float* dst = cpart + slot * C * 2 + c8 * 8;          // planar: [C] sums of dz, then [C] sums of dz*xhat
+            *(f32x4*)dst = f32x4{a0[0], a0[1], a0[2], a0[3]};
+            *(f32x4*)(dst + 4) = f32x4{a0[4], a0[5], a0[6], a0[7]};
+            *(f32x4*)(dst + C) = f32x4{a1[0], a1[1], a1[2], a1[3]};
+            *(f32x4*)(dst + C + 4) = f32x4{a1[4], a1[5], a1[6], a1[7]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a0[e] *= sc[e]; a1[e] *= sc[e]; }
         }
@@ -143,8 +160,7 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
     int r_end = r_begin + rows_per_block;
     if (r_end > HW) r_end = HW;
     const size_t base = (size_t)b * HW * C + c8 * 8;
-    for (int r = r_begin + rp; r < r_end; r += rpar) {
-        const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)r * C);
+    auto apply = [&](const bf16x8& xv, int r) {
         bf16x8 ov;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -153,39 +169,16 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
             ov[e] = (bf16_t)z;
         }
         *(bf16x8*)(y + base + (size_t)r * C) = ov;
+    };
+    int r = r_begin + rp;
+    for (; r + 3 * rpar < r_end; r += 4 * rpar) {
+        bf16x8 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = *(const bf16x8*)(x + base + (size_t)(r + u * rpar) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) apply(xv[u], r + u * rpar);
     }
-}
-
-// dgamma[c], dbeta[c] = sums over all (sample, strip) rows of cpart[row][c][1], cpart[row][c][0].
-// grid = ceil(C/64), 256 threads = 64 channels x 4 row phases.
-__global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __restrict__ cpart, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int rows, int C) {
-    __shared__ float red[4][64][2];
-    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C) {
-        const float* src = cpart + (size_t)c * 2;
-        int r = ph;
-        for (; r + 12 < rows; r += 16) {
-            const float2 v0 = *(const float2*)(src + (size_t)r * C * 2);
-            const float2 v1 = *(const float2*)(src + (size_t)(r + 4) * C * 2);
-            const float2 v2 = *(const float2*)(src + (size_t)(r + 8) * C * 2);
-            const float2 v3 = *(const float2*)(src + (size_t)(r + 12) * C * 2);
-            s0 += (v0.x + v1.x) + (v2.x + v3.x);
-            s1 += (v0.y + v1.y) + (v2.y + v3.y);
-        }
-        for (; r < rows; r += 4) {
-            const float2 v = *(const float2*)(src + (size_t)r * C * 2);
-            s0 += v.x; s1 += v.y;
-        }
-    }
-    red[ph][cl][0] = s0; red[ph][cl][1] = s1;
-    __syncthreads();
-    if (ph == 0 && c < C) {
-        dbeta[c] = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
-        dgamma[c] = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
-    }
+    for (; r < r_end; r += rpar) apply(*(const bf16x8*)(x + base + (size_t)r * C), r);
 }
 
 __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -214,9 +207,7 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
         m2[e] = gs[g * 2 + 1] * inv_n;
     }
     const size_t base = (size_t)b * HW * C + c8 * 8;
-    for (int r = r_begin + rp; r < r_end; r += rpar) {
-        const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)r * C);
-        const bf16x8 dv = *(const bf16x8*)(dy + base + (size_t)r * C);
+    auto apply = [&](const bf16x8& xv, const bf16x8& dv, int r) {
         bf16x8 ov;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -226,7 +217,20 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
             ov[e] = (bf16_t)(rs[e] * (ga[e] * dz - m1[e] - xh * m2[e]));
         }
         *(bf16x8*)(dx + base + (size_t)r * C) = ov;
+    };
+    int r = r_begin + rp;
+    for (; r + 3 * rpar < r_end; r += 4 * rpar) {
+        bf16x8 xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = *(const bf16x8*)(x + base + (size_t)(r + u * rpar) * C);
+            dv[u] = *(const bf16x8*)(dy + base + (size_t)(r + u * rpar) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) apply(xv[u], dv[u], r + u * rpar);
     }
+    for (; r < r_end; r += rpar)
+        apply(*(const bf16x8*)(x + base + (size_t)r * C), *(const bf16x8*)(dy + base + (size_t)r * C), r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,7 +427,8 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
                        (const bf16_t*)dy, stats, gamma, beta, gpart, cpart, HW, C, G, rows, silu);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st,
                        (const bf16_t*)x, (const bf16_t*)dy, stats, gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu);
-    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 63) / 64), dim3(256), 0, st, cpart, dgamma, dbeta, B * strips, C);
+    // dbeta = column sums of the first plane, dgamma of the second
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B * strips, 2 * C, dgamma, C);
     return mi355_check_launch("groupnorm_bwd");
 }
 
