@@ -34,16 +34,28 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return bf16x8{a[0],
 // 16-lane group touches must sit 64 B apart modulo the 256 B bank row.
 __host__ __device__ constexpr int tr_ld(int no) { return (no * 64) % 128 == 64 ? no * 64 : no * 64 + 64; }
 
-// Cooperative copy of `nrows` x `ncols8` 16-byte chunks into LDS; rows >= rows_valid and columns >= D
-// are zero filled.
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int rows_valid, int D, char* dst,
-                                           int dst_ld, int nrows, int ncols8) {
+// Cooperative copy of `nrows` x `ncols8` 16-byte chunks into LDS (rows >= rows_valid and columns >= D are zero
+// filled), split in two so the global loads of the NEXT tile are in flight while the current tile is
+// being multiplied: tile_load() fills NCH registers per thread (chunk idx = threadIdx.x + 256*i), tile_store()
+// writes them to LDS after the barrier that retires the current tile.
+template <int NCH>
+__device__ __forceinline__ void tile_load(bf16x8 (&reg)[NCH], const bf16_t* __restrict__ src, int ld, int rows_valid, int D,
+                                          int nrows, int ncols8) {
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int idx = threadIdx.x; idx < nrows * ncols8; idx += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int idx = threadIdx.x + 256 * i;
         const int r = idx / ncols8, c = idx - r * ncols8;
-        bf16x8 v = zero8;
-        if (r < rows_valid && c * 8 < D) v = *(const bf16x8*)(src + (size_t)r * ld + c * 8);
-        *(bf16x8*)(dst + r * dst_ld + c * 16) = v;
+        reg[i] = (idx < nrows * ncols8 && r < rows_valid && c * 8 < D) ? *(const bf16x8*)(src + (size_t)r * ld + c * 8) : zero8;
+    }
+}
+template <int NCH>
+__device__ __forceinline__ void tile_store(const bf16x8 (&reg)[NCH], char* dst, int dst_ld, int nrows, int ncols8) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int r = idx / ncols8, c = idx - r * ncols8;
+        if (idx < nrows * ncols8) *(bf16x8*)(dst + r * dst_ld + c * 16) = reg[i];
     }
 }
 
@@ -84,12 +96,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     float m = -INFINITY, l = 0.f;
 
     const int nkt = (p.Nk + 63) / 64;
+    constexpr int NCK = (64 * (DP / 8) + 255) / 256, NCV = (64 * NO * 4 + 255) / 256;
+    bf16x8 kreg[NCK], vreg[NCV];
+    tile_load(kreg, Kb, p.ldk, p.Nk, p.D, 64, DP / 8);
+    tile_load(vreg, Vb, p.ldv, p.Nk, p.D, 64, NO * 4);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
-        stage_tile(Kb + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, p.D, Ks, KLD, 64, DP / 8);
-        stage_tile(Vb + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, p.D, Vs, VLD, 64, NO * 4);
+        tile_store(kreg, Ks, KLD, 64, DP / 8);
+        tile_store(vreg, Vs, VLD, 64, NO * 4);
         __syncthreads();
+        if (kt + 1 < nkt) {                       // next tile's loads fly under this tile's MFMAs and softmax
+            tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, p.Nk - k0 - 64, p.D, 64, DP / 8);
+            tile_load(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, p.Nk - k0 - 64, p.D, 64, NO * 4);
+        }
 
         f32x16 s[2];
 #pragma unroll
@@ -176,25 +196,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
 }
 
-// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
-__global__ void attn_delta_kernel(const AttnArgs p) {
-    const size_t total = (size_t)p.B * p.Nq * p.H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int h = (int)(i % p.H);
-        const size_t row = i / p.H;      // b*Nq + q
-        const bf16_t* o = p.o + row * p.ldo + h * p.D;
-        const bf16_t* g = p.dout + row * p.ldo + h * p.D;
-        float s = 0.f;
-        for (int d = 0; d < p.D; d += 8) {
-            const bf16x8 a = *(const bf16x8*)(o + d), c = *(const bf16x8*)(g + d);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
-        }
-        const size_t bq = row / p.Nq, q = row - bq * p.Nq;
-        p.delta[(bq * p.H + h) * p.Nq + q] = s;
-    }
-}
-
 // =============================================================================================
 // backward: dK, dV.  Workgroup = 128 keys of one (b,h) (32 per wave); loops over 32-query tiles.
 // =============================================================================================
@@ -236,19 +237,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
     const int tr_row = 4 * hh + ((lane & 15) >> 2);
     const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
     const int nqt = (p.Nq + 31) / 32;
+    constexpr int NCQ = (32 * NO * 4 + 255) / 256;
+    bf16x8 qreg[NCQ], greg[NCQ];
+    float lreg = 0.f;
+    auto load_stats = [&](int q0) {
+        if (threadIdx.x < 64) {
+            const int qi = q0 + (threadIdx.x & 31);
+            lreg = 0.f;
+            if (qi < p.Nq) lreg = threadIdx.x < 32 ? lse[qi] : dlt[qi];
+            else if (threadIdx.x < 32) lreg = INFINITY;     // padded query rows: p = exp2(-inf) = 0
+        }
+    };
+    tile_load(qreg, Qb, p.ldq, p.Nq, p.D, 32, NO * 4);
+    tile_load(greg, Gb, p.ldo, p.Nq, p.D, 32, NO * 4);
+    load_stats(0);
     for (int qt = 0; qt < nqt; ++qt) {
         const int q0 = qt * 32;
         __syncthreads();
-        stage_tile(Qb + (size_t)q0 * p.ldq, p.ldq, p.Nq - q0, p.D, Qs, TLD, 32, NO * 4);
-        stage_tile(Gb + (size_t)q0 * p.ldo, p.ldo, p.Nq - q0, p.D, Gs, TLD, 32, NO * 4);
-        if (threadIdx.x < 64) {
-            const int qi = q0 + (threadIdx.x & 31);
-            float v = 0.f;
-            if (qi < p.Nq) v = threadIdx.x < 32 ? lse[qi] : dlt[qi];
-            else if (threadIdx.x < 32) v = INFINITY;     // padded query rows: p = exp2(-inf) = 0
-            Ls[threadIdx.x] = v;
-        }
+        tile_store(qreg, Qs, TLD, 32, NO * 4);
+        tile_store(greg, Gs, TLD, 32, NO * 4);
+        if (threadIdx.x < 64) Ls[threadIdx.x] = lreg;
         __syncthreads();
+        if (qt + 1 < nqt) {
+            tile_load(qreg, Qb + (size_t)(q0 + 32) * p.ldq, p.ldq, p.Nq - q0 - 32, p.D, 32, NO * 4);
+            tile_load(greg, Gb + (size_t)(q0 + 32) * p.ldo, p.ldo, p.Nq - q0 - 32, p.D, 32, NO * 4);
+            load_stats(q0 + 32);
+        }
 
         f32x16 s, dp;
 #pragma unroll
@@ -334,7 +348,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
         gf[ks] = ok ? *(const bf16x8*)(Gb + (size_t)qrow * p.ldo + d) : zero8;
     }
     const float lse = q_ok ? p.lse[((size_t)b * p.H + h) * p.Nq + qrow] : INFINITY;
-    const float dlt = q_ok ? p.delta[((size_t)b * p.H + h) * p.Nq + qrow] : 0.f;
+    // delta[q] = sum_d dO[q][d] * O[q][d]: this pass owns every query row once, so it also produces the row
+    // sums the dK/dV pass (launched after it) reads
+    float dlt = 0.f;
+    {
+        const bf16_t* Ob = p.o + (size_t)b * p.Nq * p.ldo + h * p.D;
+#pragma unroll
+        for (int ks = 0; ks < ND; ++ks) {
+            const int d = ks * 16 + 8 * hh;
+            if (q_ok && d < p.D) {
+                const bf16x8 ov = *(const bf16x8*)(Ob + (size_t)qrow * p.ldo + d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dlt += (float)ov[e] * (float)gf[ks][e];
+            }
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (q_ok && hh == 0) p.delta[((size_t)b * p.H + h) * p.Nq + qrow] = dlt;
+    }
     f32x16 dqT[NO];
 #pragma unroll
     for (int i = 0; i < NO; ++i)
@@ -344,12 +374,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
     const int tr_row = 4 * hh + ((lane & 15) >> 2);
     const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
     const int nkt = (p.Nk + 63) / 64;
+    constexpr int NCK = (64 * NO * 4 + 255) / 256, NCV = (64 * (DP / 8) + 255) / 256;
+    bf16x8 kreg[NCK], vreg[NCV];
+    tile_load(kreg, Kb, p.ldk, p.Nk, p.D, 64, NO * 4);
+    tile_load(vreg, Vb, p.ldv, p.Nk, p.D, 64, DP / 8);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
-        stage_tile(Kb + (size_t)k0 * p.ldk, p.ldk, p.Nk - k0, p.D, Ks, KLD, 64, NO * 4);
-        stage_tile(Vb + (size_t)k0 * p.ldv, p.ldv, p.Nk - k0, p.D, Vs, VLD, 64, DP / 8);
+        tile_store(kreg, Ks, KLD, 64, NO * 4);
+        tile_store(vreg, Vs, VLD, 64, DP / 8);
         __syncthreads();
+        if (kt + 1 < nkt) {
+            tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, p.Nk - k0 - 64, p.D, 64, NO * 4);
+            tile_load(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, p.Nk - k0 - 64, p.D, 64, DP / 8);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
@@ -403,12 +441,9 @@ static int launch_fwd(const AttnArgs& a, hipStream_t s) {
 }
 template <int ND, int NO>
 static int launch_bwd(const AttnArgs& a, hipStream_t s) {
-    const size_t total = (size_t)a.B * a.Nq * a.H;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<ND, NO>), dim3((a.Nk + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    // dQ first: it writes delta (row sums of dO * O), which the dK/dV pass consumes
     hipLaunchKernelGGL((attn_bwd_dq_kernel<ND, NO>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<ND, NO>), dim3((a.Nk + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
     return mi355_check_launch("attn_bwd");
 }
 
