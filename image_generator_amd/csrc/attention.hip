@@ -197,15 +197,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // =============================================================================================
-// backward: dK, dV.  Workgroup = 128 keys of one (b,h) (32 per wave); loops over 32-query tiles.
+// backward: dK, dV.  Workgroup = 128 keys of one (b,h) (32 per wave); loops over 64-query tiles.
 // =============================================================================================
 template <int ND, int NO>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p) {
-    constexpr int TLD = tr_ld(NO);      // Q / dO tiles [32][NO*32], row + transposed reads
-    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * TLD + 64 * 4];
+    constexpr int TLD = tr_ld(NO);      // Q / dO tiles [QT][NO*32], row + transposed reads
+    constexpr int QT = 64;              // queries per staged tile (two 32-query MFMA sub-tiles per barrier pair)
+    __shared__ __attribute__((aligned(16))) char smem[2 * QT * TLD + 2 * QT * 4];
     char* Qs = smem;
-    char* Gs = smem + 32 * TLD;
-    float* Ls = (float*)(smem + 2 * 32 * TLD);   // lse2[32], delta[32]
+    char* Gs = smem + QT * TLD;
+    float* Ls = (float*)(smem + 2 * QT * TLD);   // lse2[QT], delta[QT]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -236,33 +237,38 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
 
     const int tr_row = 4 * hh + ((lane & 15) >> 2);
     const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
-    const int nqt = (p.Nq + 31) / 32;
-    constexpr int NCQ = (32 * NO * 4 + 255) / 256;
+    const int nqt = (p.Nq + QT - 1) / QT;
+    constexpr int NCQ = (QT * NO * 4 + 255) / 256;
     bf16x8 qreg[NCQ], greg[NCQ];
     float lreg = 0.f;
     auto load_stats = [&](int q0) {
-        if (threadIdx.x < 64) {
-            const int qi = q0 + (threadIdx.x & 31);
+        if (threadIdx.x < 2 * QT) {
+            const int qi = q0 + (threadIdx.x & (QT - 1));
             lreg = 0.f;
-            if (qi < p.Nq) lreg = threadIdx.x < 32 ? lse[qi] : dlt[qi];
-            else if (threadIdx.x < 32) lreg = INFINITY;     // padded query rows: p = exp2(-inf) = 0
+            if (qi < p.Nq) lreg = threadIdx.x < QT ? lse[qi] : dlt[qi];
+            else if (threadIdx.x < QT) lreg = INFINITY;     // padded query rows: p = exp2(-inf) = 0
         }
     };
-    tile_load(qreg, Qb, p.ldq, p.Nq, p.D, 32, NO * 4);
-    tile_load(greg, Gb, p.ldo, p.Nq, p.D, 32, NO * 4);
+    tile_load(qreg, Qb, p.ldq, p.Nq, p.D, QT, NO * 4);
+    tile_load(greg, Gb, p.ldo, p.Nq, p.D, QT, NO * 4);
     load_stats(0);
     for (int qt = 0; qt < nqt; ++qt) {
-        const int q0 = qt * 32;
+        const int q0 = qt * QT;
         __syncthreads();
-        tile_store(qreg, Qs, TLD, 32, NO * 4);
-        tile_store(greg, Gs, TLD, 32, NO * 4);
-        if (threadIdx.x < 64) Ls[threadIdx.x] = lreg;
+        tile_store(qreg, Qs, TLD, QT, NO * 4);
+        tile_store(greg, Gs, TLD, QT, NO * 4);
+        if (threadIdx.x < 2 * QT) Ls[threadIdx.x] = lreg;
         __syncthreads();
         if (qt + 1 < nqt) {
-            tile_load(qreg, Qb + (size_t)(q0 + 32) * p.ldq, p.ldq, p.Nq - q0 - 32, p.D, 32, NO * 4);
-            tile_load(greg, Gb + (size_t)(q0 + 32) * p.ldo, p.ldo, p.Nq - q0 - 32, p.D, 32, NO * 4);
-            load_stats(q0 + 32);
+            tile_load(qreg, Qb + (size_t)(q0 + QT) * p.ldq, p.ldq, p.Nq - q0 - QT, p.D, QT, NO * 4);
+            tile_load(greg, Gb + (size_t)(q0 + QT) * p.ldo, p.ldo, p.Nq - q0 - QT, p.D, QT, NO * 4);
+            load_stats(q0 + QT);
         }
+#pragma unroll
+        for (int qs = 0; qs < QT / 32; ++qs) {
+        const char* Qt = Qs + qs * 32 * TLD;
+        const char* Gt = Gs + qs * 32 * TLD;
+        const float* Lt = Ls + qs * 32;
 
         f32x16 s, dp;
 #pragma unroll
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
 #pragma unroll
         for (int ks = 0; ks < ND; ++ks) {
             const int off = l31 * TLD + (ks * 16 + 8 * hh) * 2;
-            const bf16x8 aq = *(const bf16x8*)(Qs + off);
-            const bf16x8 ag = *(const bf16x8*)(Gs + off);
+            const bf16x8 aq = *(const bf16x8*)(Qt + off);
+            const bf16x8 ag = *(const bf16x8*)(Gt + off);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vf[ks], dp, 0, 0, 0);
         }
@@ -279,9 +285,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float pv = EXP2(fmaf(s[r], p.scale_log2, -Ls[qi]));
+            float pv = EXP2(fmaf(s[r], p.scale_log2, -Lt[qi]));
             if (!k_ok) pv = 0.f;
-            const float dsv = pv * (dp[r] - Ls[32 + qi]);
+            const float dsv = pv * (dp[r] - Lt[QT + qi]);
             pf[r >> 3][r & 7] = (bf16_t)pv;
             dsf[r >> 3][r & 7] = (bf16_t)dsv;
         }
@@ -290,11 +296,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const int off = (16 * st + tr_row) * TLD + db * 64 + tr_col;
-                const bf16x8 ag = cat4(LDS_TR(Gs + off), LDS_TR(Gs + off + 8 * TLD));
+                const bf16x8 ag = cat4(LDS_TR(Gt + off), LDS_TR(Gt + off + 8 * TLD));
                 dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, pf[st], dvT[db], 0, 0, 0);
-                const bf16x8 aq = cat4(LDS_TR(Qs + off), LDS_TR(Qs + off + 8 * TLD));
+                const bf16x8 aq = cat4(LDS_TR(Qt + off), LDS_TR(Qt + off + 8 * TLD));
                 dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, dsf[st], dkT[db], 0, 0, 0);
             }
+        }
     }
     if (k_ok) {
         bf16_t* dK = p.dk + ((size_t)b * p.Nk + key) * p.ldk + h * p.D;
