@@ -386,6 +386,8 @@ class UNet2DConditionModel(nn.Module):
 
     def _build_flat(self):
         params = list(self.parameters())
+        self._plist = params                    # cached: walking the module tree on every forward costs milliseconds
+        self._resnets = [m for m in self.modules() if isinstance(m, ResnetBlock)]
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("UNet2DConditionModel: parameters must live on the HIP device (no CPU path)")
@@ -485,7 +487,7 @@ class UNet2DConditionModel(nn.Module):
             self._build_flat()
 
     def _signature(self):
-        return tuple(p._version for p in self.parameters())
+        return tuple(p._version for p in self._plist)
 
     def refresh_operands(self, cast=True):
         """Re-derive every bf16 operand from the fp32 masters (call after the parameters changed)."""
@@ -580,7 +582,7 @@ class UNet2DConditionModel(nn.Module):
         t_emb = ops.timestep_embedding(t, cfg.block_out_channels[0])
         emb = self.time_embedding(t_emb)                 # [B, 4*C0] fp32
         temb_act = SiluF32ToBf16Fn.apply(emb)            # shared by every residual block
-        resnets = [m for m in self.modules() if isinstance(m, ResnetBlock)] if self._temb_pack is not None else []
+        resnets = self._resnets if self._temb_pack is not None else []
         if resnets:
             tl = self._temb_layers
             tproj = LinearFn.apply(temb_act, self._temb_pack, self._temb_bias, None, True,
