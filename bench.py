@@ -140,7 +140,7 @@ def main():
         if prof:
             gp = prof["gemm_conv"]
             tf = gp["work_per_step"] / (gp["ms_per_step"] * 1e-3) / 1e12 if gp["ms_per_step"] > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "gemm_kernel (implicit-GEMM conv + linear, fwd and dgrad)",
+            roof = {"bound": "mfma", "kernel": "gemm_dma_kernel family (implicit-GEMM conv + linear, fwd and dgrad)",
                     "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
                     "traffic": None,
                     "avg_launch_us": gp["ms_per_step"] * 1e3 / max(1.0, gp["launches_per_step"]),
