@@ -13,6 +13,7 @@ step on a bounded sample, rank 0, N = 1 only).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -106,6 +107,7 @@ def main():
     for i in range(args.warmup):
         loss = step(i)
     barrier()
+    probe = trainer.opt.flat[:65536].clone()      # to prove afterwards that the timed steps really updated the weights
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -118,6 +120,9 @@ def main():
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     final_loss = float(loss)
+    gnorm = trainer.opt.grad_norm()
+    if not (math.isfinite(final_loss) and math.isfinite(gnorm) and gnorm > 0) or torch.equal(probe, trainer.opt.flat[:65536]):
+        raise RuntimeError(f"invalid measurement: optimizer skipped or diverged (loss {final_loss}, grad norm {gnorm})")
 
     # contraction-kernel roofline: HIP events on the launch stream around every GEMM / conv / wgrad /
     # attention launch of `prof_steps` further steps of the same workload
@@ -157,7 +162,7 @@ def main():
                "config": {"workload": "denoiser train step 256x256 (latent 32x32), SD-v1 UNet 859.5M params, "
                                       "text cross-attention T=77" if not args.small else "small plumbing model",
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                          "optimizer": "fused AdamW + global-norm clip", "final_loss": final_loss,
+                          "optimizer": "fused AdamW + global-norm clip", "final_loss": final_loss, "final_grad_norm": gnorm,
                           "hip_graph": bool(graphed)},
                "step_mfma_frac": step_flops / (ms * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12) if not args.small else None,
                "roofline": roof}

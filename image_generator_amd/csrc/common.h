@@ -60,6 +60,25 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // out[s][n] = sum_r partial[s][r][n]; launch with grid (ceil(N/64), nseg), 256 threads (64 columns x 4 row phases).
 // (static: every translation unit that launches it carries its own copy; no relocatable device code needed)
+// Zero fill by a kernel.  hipMemsetAsync must not be used on a path that can be captured into a hipGraph:
+// on this stack a captured memset node zeroes correctly on the first replay only (later replays leave garbage),
+// which silently corrupts anything that accumulates into the buffer.
+static __global__ void zero_fill_kernel(char* __restrict__ p, size_t bytes) {
+    const size_t n16 = bytes >> 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        *(f32x4*)(p + (i << 4)) = z;
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) p[(n16 << 4) + threadIdx.x] = 0;
+}
+// p must be 16-byte aligned (every buffer of this library is).
+static inline void mi355_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return;
+    size_t blocks = ((bytes >> 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (char*)p, bytes);
+}
+
 // out[s][col] = sum over r < R of partial[s][r][col].  With out_hi != nullptr, columns >= split are written to
 // out_hi[col - split] instead (two destinations from one planar [R][2][C] partial buffer; single segment).
 static __global__ void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int R, int N,

@@ -579,7 +579,7 @@ int mi355_sumpool2x2_bf16(const void* dy, void* dx, int B, int H, int W, int C, 
 // loss must point at one float; it is zeroed here.
 int mi355_mse_loss_fused(const float* pred, const float* target, float* grad, float* loss, long long n, void* stream) {
     if (!pred || !target || !loss || n <= 0) return mi355_fail(MI355_ERR_ARG, "mse_loss: bad arguments");
-    if (hipMemsetAsync(loss, 0, sizeof(float), ST) != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "mse_loss: memset failed");
+    mi355_zero_async(loss, sizeof(float), ST);
     ProfScope prof(FAM_ELEM, ST, (double)n * 12);
     hipLaunchKernelGGL(mse_fused_kernel, dim3(GRID_FOR(n, 1024)), dim3(256), 0, ST, pred, target, grad, loss, (size_t)n);
     return mi355_check_launch("mse_loss_fused");
@@ -605,8 +605,9 @@ int mi355_sumsq_f32(const float* g, float* out, long long n, void* stream) {
 }
 int mi355_zero_f32(float* p, long long n, void* stream) {
     if (!p) return mi355_fail(MI355_ERR_ARG, "zero: null pointer");
-    if (hipMemsetAsync(p, 0, (size_t)n * sizeof(float), ST) != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "zero: memset failed");
-    return MI355_OK;
+    if (((uintptr_t)p) & 15) return mi355_fail(MI355_ERR_ARG, "zero: buffer must be 16-byte aligned");
+    mi355_zero_async(p, (size_t)n * sizeof(float), ST);
+    return mi355_check_launch("zero");
 }
 int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
                      long long n, void* stream) {
@@ -630,8 +631,8 @@ int mi355_contrastive_loss_fused(const float* text, const float* image, const fl
     if (B <= 0 || D <= 0 || D > 12288) return mi355_fail(MI355_ERR_ARG, "contrastive: bad shape");
     float* th = scratch; float* ih = th + (size_t)B * D; float* tn = ih + (size_t)B * D; float* in_ = tn + B;
     float* logits = in_ + B; float* lse = logits + (size_t)B * B;
-    hipMemsetAsync(loss, 0, sizeof(float), ST);
-    hipMemsetAsync(d_log_temp, 0, sizeof(float), ST);
+    mi355_zero_async(loss, sizeof(float), ST);
+    mi355_zero_async(d_log_temp, sizeof(float), ST);
     ProfScope prof(FAM_ELEM, ST, 6.0 * B * B * D);
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, ST, text, th, tn, B, D);
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, ST, image, ih, in_, B, D);
@@ -658,7 +659,7 @@ int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int 
 int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int out_transposed,
                      void* stream) {
     if (!y || !t || !out || (C & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_outer: bad arguments");
-    if (hipMemsetAsync(out, 0, (size_t)C * R * sizeof(float), ST) != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "lora_outer: memset failed");
+    mi355_zero_async(out, (size_t)C * R * sizeof(float), ST);
     const int rows = 128;
     hipLaunchKernelGGL(lora_outer_kernel, dim3((M + rows - 1) / rows), dim3(128), 0, ST, (const bf16_t*)y, t, out, M, C, R, scale, rows, out_transposed);
     return mi355_check_launch("lora_outer");

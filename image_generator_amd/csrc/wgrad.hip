@@ -679,12 +679,8 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
     //             2 = dw and dbias were zeroed by the caller (plain stores when unsplit, no memsets here)
     a.use_atomic = (a.splits > 1 || accumulate == 1) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (a.splits > 1 && accumulate == 0) {
-        hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * a.taps * Cin * sizeof(float), st);
-        if (e != hipSuccess) return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed: %s", hipGetErrorString(e));
-    }
-    if (dbias && accumulate == 0 && hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st) != hipSuccess)
-        return mi355_fail(MI355_ERR_LAUNCH, "wgrad: memset failed");
+    if (a.splits > 1 && accumulate == 0) mi355_zero_async(dw, (size_t)Cout * a.taps * Cin * sizeof(float), st);
+    if (dbias && accumulate == 0) mi355_zero_async(dbias, (size_t)Cout * sizeof(float), st);
     ProfScope prof(FAM_WGRAD, st, 2.0 * a.M * Cout * (double)a.taps * Cin);
     if (dma)
         hipLaunchKernelGGL(wgrad_dma_kernel, dim3(wgrad_dma_blocks(a)), dim3(256), 0, st, a);

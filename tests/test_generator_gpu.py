@@ -181,8 +181,14 @@ def test_graphed_step_matches_eager_step():
         tr = DenoiserTrainer(unet, lr=1e-3)
         if graphed:
             tr.capture(lat, noise, ts, ctx)
-        losses.append([float(tr.train_step(lat, noise, ts, ctx, epoch_float=1.0 + 0.1 * i)) for i in range(3)])
+        run = []
+        for i in range(5):
+            run.append(float(tr.train_step(lat, noise, ts, ctx, epoch_float=1.0 + 0.1 * i)))
+            gn = tr.opt.grad_norm()
+            assert math.isfinite(gn) and gn > 0, (graphed, i, gn)       # a non-finite norm would skip the update
+        losses.append(run)
     assert losses[0][2] < losses[0][0]                      # the optimizer makes progress
+    assert losses[1][4] < losses[1][0]
     assert abs(losses[0][0] - losses[1][0]) <= 1e-6 * abs(losses[0][0]), losses
     for a, b in zip(*losses):
         assert abs(a - b) <= 1e-3 * abs(a), losses
@@ -211,3 +217,29 @@ def test_deferred_grouped_wgrad_matches_immediate():
     rel = float((grads[0] - grads[1]).norm() / grads[0].norm())
     assert rel <= 1e-3, rel
     assert float(grads[1].abs().max()) > 0
+
+
+def test_replayed_graph_rezeroes_accumulators():
+    """Every replay of a captured graph must re-zero what a kernel accumulates into (split weight-gradient tiles,
+    bias sums, loss scalars): the library zeroes with kernels, because captured memset nodes were seen to
+    zero on the first replay only."""
+    from image_generator_amd import ops
+    B, H, C, Co = 8, 32, 8, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, H, C, generator=g).to(D).to(torch.bfloat16)
+    dy = torch.randn(B, H, H, Co, generator=g).to(D).to(torch.bfloat16)
+    ref = ops.wgrad(dy, x, C, Co, 3, 1, False, geom=(B, H, H, H, H)).clone()
+    pred, tgt = torch.randn(4096, generator=g).to(D), torch.randn(4096, generator=g).to(D)
+    loss_ref = float(ops.mse_loss(pred, tgt))
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        junk = torch.full((1 << 20,), 123.0, device=D)       # dirties the pool memory the outputs will reuse
+        del junk
+        out = ops.wgrad(dy, x, C, Co, 3, 1, False, geom=(B, H, H, H, H))
+        loss = ops.mse_loss(pred, tgt)
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert float((out - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+        assert abs(float(loss) - loss_ref) <= 1e-5 * abs(loss_ref)
