@@ -150,11 +150,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             }
         sum += __shfl_xor(sum, 32, 64);
         l = l * alpha + sum;
+        // the running maximum settles after a few tiles: rescale only when some query of the wave moved it
+        if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {
+#pragma unroll
+            for (int i = 0; i < NO; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
         m = m_new;
-#pragma unroll
-        for (int i = 0; i < NO; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 
         bf16x8 pf[2][2];
 #pragma unroll
