@@ -169,6 +169,47 @@ class FusedAdamW:
         """Host read of the last step's pre-clip global gradient norm (synchronises)."""
         return float(self.state[0].sqrt() * self.hyper[8])
 
+    # ---- torch.optim.AdamW-shaped state (what `optimizer.state_dict()` holds in the reference checkpoint,
+    # trainer.py:139-153): per-parameter `step`, `exp_avg`, `exp_avg_sq`, indexed in `unet.parameters()` order
+    def _param_views(self, flat):
+        views = []
+        for p in self.unet.parameters():
+            o, n = self.unet._offs[id(p)], p.numel()
+            if p.dim() == 4:
+                co, ci, kh, kw = p.shape
+                views.append(flat[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2))
+            else:
+                views.append(flat[o:o + n].view(p.shape))
+        return views
+
+    def state_dict(self):
+        ms, vs = self._param_views(self.m), self._param_views(self.v)
+        state = {i: {"step": torch.tensor(float(self.t)), "exp_avg": m.detach().cpu().contiguous(),
+                     "exp_avg_sq": v.detach().cpu().contiguous()} for i, (m, v) in enumerate(zip(ms, vs))}
+        # the installed torch's own AdamW supplies the param-group keys, so the file loads into a torch optimizer too
+        group = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(()))], lr=self.lr, betas=tuple(self.betas), eps=self.eps,
+                                  weight_decay=self.wd).state_dict()["param_groups"][0]
+        group["params"] = list(range(len(ms)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        ms, vs = self._param_views(self.m), self._param_views(self.v)
+        if len(sd["state"]) not in (0, len(ms)):
+            raise ValueError(f"optimizer state has {len(sd['state'])} entries, the model has {len(ms)} parameters")
+        steps = set()
+        for i, st in sd["state"].items():
+            i = int(i)
+            if tuple(st["exp_avg"].shape) != tuple(ms[i].shape):
+                raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(ms[i].shape)}")
+            ms[i].copy_(st["exp_avg"])
+            vs[i].copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("optimizer state with per-parameter step counts is not supported (one fused step counter)")
+        self.t = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+
 
 class DenoiserTrainer:
     """One data-parallel denoiser train step: add-noise -> UNet -> fused MSE -> backward with overlapped
@@ -222,7 +263,54 @@ class DenoiserTrainer:
             return self._replay(latents, noise, t, ctx, lr)
         loss = self.forward_backward(latents, noise, t, ctx)
         self.opt.step(lr=lr, grad_prescale=1.0 / self.world)
+        self.step_count += 1
         return loss
+
+    # ---- files (reference trainer.py:123-189): `weights/<name>` holds unet.state_dict(), `checkpoints/<name>` the
+    # {"model", "optimizer", "step", "loss", "epoch"} dictionary; rank 0 writes, every rank loads
+    step_count = 0
+    best_loss = float("inf")
+
+    def save_weights(self, output_dir, name="unet.pth"):
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return None
+        d = os.path.join(str(output_dir), "weights")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, name)
+        torch.save({k: v.detach().cpu() for k, v in self.unet.state_dict().items()}, path)
+        return path
+
+    def save_checkpoint(self, output_dir, epoch, name="checkpoint.pth"):
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return None
+        d = os.path.join(str(output_dir), "checkpoints")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, name)
+        torch.save({"model": {k: v.detach().cpu() for k, v in self.unet.state_dict().items()},
+                    "optimizer": self.opt.state_dict(), "step": self.step_count, "loss": self.best_loss,
+                    "epoch": epoch}, path)
+        print(f"[INFO] Saved checkpoint to {path}")
+        return path
+
+    def load_checkpoint(self, path):
+        """Returns the epoch to resume from, or None (with the reference's error message) when the file is missing
+        or does not fit the model.  Tensors only: the file is read with `weights_only=True`."""
+        if not os.path.exists(path):
+            print(f"[ERROR] Checkpoint file {path} not found!")
+            return None
+        try:
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+            self.unet.load_state_dict(ck["model"])
+            self.opt.load_state_dict(ck["optimizer"])
+            self.unet.refresh_operands()
+            self.step_count = ck["step"] + 1
+            self.best_loss = ck["loss"]
+            self._graph = None                      # a captured step holds the old step counter's hyper-parameters
+            print(f"[INFO] Resumed from {path} | epoch: {ck['epoch']} | step: {self.step_count} | loss: {self.best_loss}")
+            return ck["epoch"]
+        except Exception as e:                      # the reference reports and carries on (trainer.py:186-189)
+            print(f"[ERROR] Failed to load checkpoint: {e}")
+            return None
 
     # ---- whole-step HIP graph (static shapes): forward, backward and optimizer replayed as one graph,
     # per-step scalars (lr, bias corrections) are staged into a device buffer before each replay
@@ -262,6 +350,7 @@ class DenoiserTrainer:
                 dst.copy_(src, non_blocking=True)
         self.opt.set_hyper(lr, grad_prescale=1.0)
         self._graph.replay()
+        self.step_count += 1
         return self._static_loss
 
 

@@ -243,3 +243,36 @@ def test_replayed_graph_rezeroes_accumulators():
         torch.cuda.synchronize()
         assert float((out - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
         assert abs(float(loss) - loss_ref) <= 1e-5 * abs(loss_ref)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """save_checkpoint / load_checkpoint (reference trainer.py:139-189 file layout): a fresh trainer that loads the
+    file continues with the same losses as the one that wrote it; the optimizer state has torch.optim.AdamW's shape."""
+    from image_generator_amd.trainer import DenoiserTrainer
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    g = torch.Generator().manual_seed(11)
+    lat, noise = torch.randn(4, 4, 8, 8, generator=g).to(D), torch.randn(4, 4, 8, 8, generator=g).to(D)
+    ts, ctx = torch.randint(0, 1000, (4,), generator=g).to(D), torch.randn(4, 16, 64, generator=g).to(D).to(torch.bfloat16)
+    torch.manual_seed(0)
+    tr = DenoiserTrainer(UNet2DConditionModel(DenoiserConfig.small()).to(D), lr=1e-3)
+    for i in range(3):
+        tr.train_step(lat, noise, ts, ctx)
+    path = tr.save_checkpoint(tmp_path, epoch=7)
+    wpath = tr.save_weights(tmp_path)
+    cont = [float(tr.train_step(lat, noise, ts, ctx)) for _ in range(3)]
+
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"model", "optimizer", "step", "loss", "epoch"} and ck["epoch"] == 7 and ck["step"] == 3
+    opt = ck["optimizer"]
+    assert set(opt) == {"state", "param_groups"} and set(opt["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ref_adamw = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(())) for _ in range(len(opt["state"]))])
+    assert set(opt["param_groups"][0]) == set(ref_adamw.state_dict()["param_groups"][0])
+    assert set(torch.load(wpath, map_location="cpu", weights_only=True)) == set(ck["model"])
+
+    torch.manual_seed(123)                                   # different initial weights: everything must come from the file
+    tr2 = DenoiserTrainer(UNet2DConditionModel(DenoiserConfig.small()).to(D), lr=1e-3)
+    assert tr2.load_checkpoint(path) == 7 and tr2.step_count == 4
+    resumed = [float(tr2.train_step(lat, noise, ts, ctx)) for _ in range(3)]
+    for a, b in zip(cont, resumed):
+        assert abs(a - b) <= 1e-3 * abs(a), (cont, resumed)
+    assert tr2.load_checkpoint(str(tmp_path / "missing.pth")) is None
