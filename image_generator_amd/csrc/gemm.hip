@@ -45,11 +45,14 @@ struct GemmArgs {
     float lora_alpha;
     float* partial;          // split-K slabs [splitk][M][N] fp32
     int splitk, kt_per_split;
+    int geglu;               // fused GEGLU (inference): N = 2F weight rows (hidden | gate), out [M][F] = h * gelu(g)
     int tiles_m, tiles_n;
     ConvGeom g;
 };
 
 enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2 };
+
+__device__ __forceinline__ float gemm_gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 // Shared tail of both GEMM kernels: split-K slab store, or the LDS-staged vectorised epilogue.
 template <int BN, int TM, int TN, int NTHREADS = 256>
@@ -88,6 +91,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         }
         __syncthreads();
         constexpr int NC = BN / 8;
+        if (p.geglu) {
+            // tile columns [0, BN/2) are hidden units f0 .. f0 + BN/2, columns [BN/2, BN) their gates
+            const int F = p.N >> 1, f0 = (n0 / BN) * (BN / 2);
+            for (int idx = tid; idx < 64 * (NC / 2); idx += NTHREADS) {
+                const int row = idx / (NC / 2), c8 = idx - row * (NC / 2);
+                const int m = m0 + h * 64 + row, f = f0 + c8 * 8;
+                if (m >= p.M || f >= F) continue;
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float hv = ep[row * EP_LD + c8 * 8 + e] * p.alpha, gv = ep[row * EP_LD + BN / 2 + c8 * 8 + e] * p.alpha;
+                    if (p.bias) { hv += p.bias[f + e]; gv += p.bias[F + f + e]; }
+                    ov[e] = (bf16_t)(hv * gemm_gelu_erf(gv));
+                }
+                *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + f) = ov;
+            }
+            continue;
+        }
         for (int idx = tid; idx < 64 * NC; idx += NTHREADS) {
             const int row = idx / NC, c8 = idx - row * NC;
             const int m = m0 + h * 64 + row, n = n0 + c8 * 8;
@@ -363,7 +384,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     int b_voff[B_P];
 #pragma unroll
     for (int j = 0; j < B_P; ++j) {
-        const int n = n0 + (wave + NW * j) * 8 + sr;
+        int n = n0 + (wave + NW * j) * 8 + sr;
+        if (p.geglu) {                       // first half of the tile: hidden rows, second half: the matching gate rows
+            const int nl = (wave + NW * j) * 8 + sr, F = p.N >> 1, f0 = tile_n * (BN / 2);
+            n = nl < BN / 2 ? f0 + nl : F + f0 + nl - BN / 2;
+            if (f0 + (nl < BN / 2 ? nl : nl - BN / 2) >= F) n = p.N;
+        }
         b_voff[j] = n < p.N ? (n * p.ldb + kc * 8) * 2 : OOB_OFF;
     }
     const int nbp = (B_PIECES - wave + NW - 1) / NW;     // B pieces of this wave (uneven when NW does not divide them)
@@ -569,8 +595,12 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     else bn = 128;
     a.tiles_m = (a.M + 127) / 128;
     a.tiles_n = (a.N + bn - 1) / bn;
+    if (a.geglu) {
+        if (bn != 160 || (a.N / 2) % 8) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_geglu: 2F = %d must be a multiple of 160", a.N);
+        a.tiles_n = (a.N / 2 + 79) / 80;
+    }
     const int nkt = (a.K + 63) / 64;
-    int sk = pick_splitk(a.tiles_m * a.tiles_n, nkt, (double)a.M * a.N, bn);
+    int sk = a.geglu ? 1 : pick_splitk(a.tiles_m * a.tiles_n, nkt, (double)a.M * a.N, bn);
     while (sk > 1 && (size_t)sk * a.M * a.N * sizeof(float) > ws_bytes) --sk;
     a.kt_per_split = (nkt + sk - 1) / sk;
     sk = (nkt + a.kt_per_split - 1) / a.kt_per_split;
@@ -585,6 +615,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     const double b_sz = ((double)(a.N - 1) * a.ldb + a.K) * 2.0;
     const bool dma_ok = !force_v1 && a.K % 64 == 0 && amode != AMODE_CONV_GENERIC && a_sz < 2.0e9 && b_sz < 2.0e9 &&
                         (double)a.M * (amode == AMODE_DENSE ? a.lda : 1) < 1.0e9;
+    if (a.geglu && !dma_ok) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_geglu: needs K %% 64 == 0 and operands < 2 GB");
     if (dma_ok) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
 #define DISPATCH_DMA(BN) (amode == AMODE_DENSE ? launch_gemm_dma<BN, AMODE_DENSE>(a, ab, bb, s) \
@@ -635,6 +666,16 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
     a.lora_t = lora_t; a.lora_b = lora_b; a.lora_r = lora_r; a.lora_alpha = lora_alpha;
     a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1};
     return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mi355_gemm_geglu_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int F, int K, void* out, int ldo,
+                          const float* bias, void* stream) {
+    if (!A || !Bw || !out) return mi355_fail(MI355_ERR_ARG, "gemm_geglu: null pointer");
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = 2 * F; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.out = out; a.ldo = ldo; a.out_fp32 = 0; a.bias = bias; a.rowbias_div = 1; a.alpha = 1.f; a.geglu = 1;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1};
+    return run_gemm(a, AMODE_DENSE, nullptr, 0, (hipStream_t)stream);
 }
 
 int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, int ksize, int stride,

@@ -70,6 +70,17 @@ def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=F
     return out
 
 
+def gemm_geglu(a, w, bias=None):
+    """out[M,F] = (a @ w[:F]^T + b[:F]) * gelu(a @ w[F:]^T + b[F:]) in one launch (no-grad path of the GEGLU block)."""
+    M, K = a.shape
+    F2 = w.shape[0]
+    assert a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.is_contiguous() and w.shape[1] == K
+    out = torch.empty((M, F2 // 2), dtype=BF16, device=a.device)
+    check(lib.mi355_gemm_geglu_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), K, M, F2 // 2, K, out.data_ptr(), F2 // 2,
+                                    _ptr(bias), _stream()), "gemm_geglu")
+    return out
+
+
 def conv2d(x, w, cout, ksize, stride=1, ups=False, dil=False, out_hw=None, bias=None, rowbias=None, residual=None,
            out_fp32=False):
     """x [B,H,W,C] bf16 NHWC; w physical [Cout][k][k][C] bf16 -> [B,Ho,Wo,Cout]."""

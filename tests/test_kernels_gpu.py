@@ -402,3 +402,18 @@ def test_lora_linear_golden(golden_dir):
         assert rel_l2(m.lora_A.weight.grad, torch.tensor(z[f"c{ci}_da"])) < 2e-2
         assert rel_l2(m.lora_B.weight.grad, torch.tensor(z[f"c{ci}_db"])) < 2e-2
         assert m.original.weight.grad is None
+
+
+def test_gemm_geglu_fused_epilogue():
+    """out = (x W_h^T + b_h) * gelu_erf(x W_g^T + b_g) in one launch (inference path of the GEGLU block) against
+    fp32 torch; 2^-7 relative on the bf16 output (the fused path keeps both halves in fp32 up to the product)."""
+    from image_generator_amd import ops
+    for (M, K, Fh) in [(300, 128, 160), (1024, 320, 1280)]:
+        x = rnd(M, K, seed=1).to(dev())
+        w = rnd(2 * Fh, K, scale=K ** -0.5, seed=2).to(dev())
+        b = rnd(2 * Fh, seed=3).float().to(dev())
+        for bias in (b, None):
+            y = ops.gemm_geglu(x, w, bias)
+            pre = x.float() @ w.float().t() + (0 if bias is None else bias)
+            ref = pre[:, :Fh] * F.gelu(pre[:, Fh:])
+            close(y, ref, 2 ** -7, 2 ** -7 * float(ref.abs().max()), f"geglu M{M} K{K} F{Fh}")
