@@ -18,6 +18,7 @@ struct AttnArgs {
     bf16_t *out, *dq, *dk, *dv;
     float* lse;            // [B][H][Nq]
     float* delta;          // [B][H][Nq]
+    const int* kv_len;     // optional [B]: keys >= kv_len[b] are masked (key-padding mask, forward only); null = all Nk
     int B, H, Nq, Nk, D;
     int ldq, ldk, ldv, ldo;
     float scale_log2;      // softmax scale * log2(e)
@@ -95,11 +96,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    const int nkt = (p.Nk + 63) / 64;
+    const int Nk = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;     // valid keys of this sample
+    const int nkt = (Nk + 63) / 64;
     constexpr int NCK = (64 * (DP / 8) + 255) / 256, NCV = (64 * NO * 4 + 255) / 256;
     bf16x8 kreg[NCK], vreg[NCV];
-    tile_load(kreg, Kb, p.ldk, p.Nk, p.D, 64, DP / 8);
-    tile_load(vreg, Vb, p.ldv, p.Nk, p.D, 64, NO * 4);
+    tile_load(kreg, Kb, p.ldk, Nk, p.D, 64, DP / 8);
+    tile_load(vreg, Vb, p.ldv, Nk, p.D, 64, NO * 4);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
@@ -107,8 +109,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         tile_store(vreg, Vs, VLD, 64, NO * 4);
         __syncthreads();
         if (kt + 1 < nkt) {                       // next tile's loads fly under this tile's MFMAs and softmax
-            tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, p.Nk - k0 - 64, p.D, 64, DP / 8);
-            tile_load(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, p.Nk - k0 - 64, p.D, 64, NO * 4);
+            tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, Nk - k0 - 64, p.D, 64, DP / 8);
+            tile_load(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, Nk - k0 - 64, p.D, 64, NO * 4);
         }
 
         f32x16 s[2];
@@ -123,13 +125,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             }
         }
         float mx = -INFINITY;
-        if (k0 + 64 > p.Nk) {            // only the last key tile can hold padded keys (wave-uniform branch)
+        if (k0 + 64 > Nk) {            // only the last key tile can hold padded keys (wave-uniform branch)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= p.Nk) s[kb][r] = -INFINITY;
+                    if (key >= Nk) s[kb][r] = -INFINITY;
                 }
         }
 #pragma unroll
@@ -478,6 +480,21 @@ int mi355_attention_fwd(const void* q, const void* k, const void* v, void* out, 
     if (!q || !k || !v || !out) return mi355_fail(MI355_ERR_ARG, "attention_fwd: null pointer");
     AttnArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    if (int rc = check_attn(a)) return rc;
+    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Nq * Nk * D);
+    return ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
+}
+
+// Forward with a key-padding mask given as valid key counts per sample (1 <= kv_len[b] <= Nk, device int32).
+int mi355_attention_fwd_masked(const void* q, const void* k, const void* v, void* out, float* lse, const int* kv_len,
+                               int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale,
+                               void* stream) {
+    if (!q || !k || !v || !out || !kv_len) return mi355_fail(MI355_ERR_ARG, "attention_fwd_masked: null pointer");
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
+    a.kv_len = kv_len;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
     if (int rc = check_attn(a)) return rc;

@@ -9,6 +9,17 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+// ---- GELU (erf form), bf16 -> bf16 (text-encoder feed-forward activation)
+__global__ void gelu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *(const bf16x8*)(in + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)gelu_f((float)v[e]);
+        *(bf16x8*)(out + i * 8) = o;
+    }
+}
+
 // ---- GEGLU: in [M][2F] (hidden | gate) -> out [M][F] = hidden * gelu(gate)
 __global__ void geglu_fwd_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, size_t M, int F) {
     const int nc = F >> 3;
@@ -504,6 +515,12 @@ extern "C" {
 
 #define ST ((hipStream_t)stream)
 
+int mi355_gelu_bf16(const void* in, void* out, long long n, void* stream) {
+    if (!in || !out || (n & 7)) return mi355_fail(MI355_ERR_ARG, "gelu: bad arguments (n must be a multiple of 8)");
+    ProfScope prof(FAM_ELEM, ST, (double)n * 4);
+    hipLaunchKernelGGL(gelu_kernel, dim3(GRID_FOR((size_t)n / 8, 256)), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, (size_t)n / 8);
+    return mi355_check_launch("gelu");
+}
 int mi355_geglu_fwd(const void* in, void* out, long long M, int F, void* stream) {
     if (!in || !out || (F & 7)) return mi355_fail(MI355_ERR_ARG, "geglu_fwd: bad arguments");
     ProfScope prof(FAM_ELEM, ST, (double)M * F * 2 * 3);

@@ -217,13 +217,20 @@ def colsum(y2d, seg=None):
     return out
 
 
-def attention_fwd(q, k, v, heads):
-    """q [B,Nq,C], k/v [B,Nk,C] (last dim contiguous; row stride arbitrary multiple of 8)."""
+def attention_fwd(q, k, v, heads, kv_len=None):
+    """q [B,Nq,C], k/v [B,Nk,C] (last dim contiguous; row stride arbitrary multiple of 8).
+    kv_len: optional int32 [B] device tensor, keys >= kv_len[b] are masked (key-padding mask)."""
     B, Nq, C = q.shape
     Nk = k.shape[1]
     D = C // heads
     out = torch.empty((B, Nq, C), dtype=BF16, device=q.device)
     lse = torch.empty((B, heads, Nq), dtype=F32, device=q.device)
+    if kv_len is not None:
+        assert kv_len.dtype == torch.int32 and kv_len.is_cuda and kv_len.numel() == B
+        check(lib.mi355_attention_fwd_masked(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                             kv_len.data_ptr(), B, heads, Nq, Nk, D, q.stride(1), k.stride(1), v.stride(1),
+                                             C, 1.0 / math.sqrt(D), _stream()), "attention_fwd_masked")
+        return out, lse
     check(lib.mi355_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, heads,
                                   Nq, Nk, D, q.stride(1), k.stride(1), v.stride(1), C, 1.0 / math.sqrt(D), _stream()),
           "attention_fwd")
@@ -240,6 +247,21 @@ def attention_bwd(q, k, v, o, do, lse, heads, dq, dk, dv):
                                   delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Nq, Nk, D,
                                   q.stride(1), k.stride(1), v.stride(1), C, 1.0 / math.sqrt(D), _stream()),
           "attention_bwd")
+
+
+def gelu_bf16(x):
+    y = torch.empty_like(x)
+    check(lib.mi355_gelu_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gelu")
+    return y
+
+
+def layernorm_bf16(x2d, gamma, beta, eps):
+    """LayerNorm over the last dim of a contiguous bf16 [M, C] matrix (forward only, no statistics kept)."""
+    M, C = x2d.shape
+    y = torch.empty_like(x2d)
+    check(lib.mi355_layernorm_fwd(x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), None, M, C, eps,
+                                  _stream()), "layernorm_fwd")
+    return y
 
 
 def cast_bf16(x_f32, out=None):

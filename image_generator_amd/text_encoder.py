@@ -8,10 +8,12 @@ reference module loads unchanged.
 
 The generator uses it frozen under no_grad (image_generator.py:56-60 semantics): post-LN encoder
 layers with GELU, key-padding mask, and - as the reference's inference path does - the rows of padded
-tokens leave the layer stack as zeros before the final LayerNorm/projection.  In training mode
-(encoder pre-training, outside the denoiser hot path) every row is computed and dropout applies.
-The arithmetic here is issued through PyTorch-ROCm tensor ops on the HIP device; moving it onto the
-library's LayerNorm/GEMM/attention kernels is the next widening step of this path.
+tokens leave the layer stack as zeros before the final LayerNorm/projection.  That inference path
+(`return_pooled=False`, no gradients, HIP device) runs on the library's kernels: fused in-projection GEMM,
+flash attention with the key-padding mask as per-sample key counts, out-projection / feed-forward GEMMs
+with the residual in the epilogue, LayerNorm and GELU kernels; bf16 activations, fp32 accumulation.
+In training mode (encoder pre-training, outside the denoiser hot path) and for the pooled output the
+arithmetic is issued through PyTorch tensor ops: every row is computed and dropout applies.
 """
 from __future__ import annotations
 
@@ -72,7 +74,54 @@ class TextEncoder(nn.Module):
         self.norm = nn.LayerNorm(embed_dim)
         self.projection = nn.Linear(embed_dim, projection_dim)
 
+    # ---- inference on the HIP kernels -----------------------------------------------------------
+    def _operands(self):
+        """bf16 copies of the GEMM weights, rebuilt when a parameter changes (the module is frozen in the generator)."""
+        sig = tuple(p._version for p in self.parameters()) + (next(self.parameters()).device,)
+        if getattr(self, "_op_sig", None) != sig:
+            from .ops import BF16
+            self._w16 = {n: p.detach().to(BF16).contiguous() for n, p in self.named_parameters()
+                         if p.dim() == 2 and not n.startswith("embedding")}
+            self._op_sig = sig
+        return self._w16
+
+    def _forward_hip(self, input_ids, attention_mask):
+        from . import ops
+        w16 = self._operands()
+        B, T = input_ids.shape
+        D = self.embedding.embedding_dim
+        H = self.transformer.layers[0].self_attn.num_heads
+        x = ops.cast_bf16(self.embedding(input_ids).contiguous()).view(B * T, D)      # gather, then fp32 -> bf16
+        kv_len = None
+        if attention_mask is not None:
+            m = attention_mask.bool()
+            kv_len = m.sum(dim=1).to(torch.int32)
+            # the kernel takes the mask as a count of leading keys: tokenizers pad on the right
+            if not bool((m == (torch.arange(T, device=m.device)[None, :] < kv_len[:, None])).all()) or int(kv_len.min()) < 1:
+                return None
+        for i, layer in enumerate(self.transformer.layers):
+            pre = f"transformer.layers.{i}."
+            sa = layer.self_attn
+            qkv = ops.gemm(x, w16[pre + "self_attn.in_proj_weight"], bias=sa.in_proj_bias).view(B, T, 3 * D)
+            a, _ = ops.attention_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H, kv_len=kv_len)
+            x = ops.gemm(a.view(B * T, D), w16[pre + "self_attn.out_proj.weight"], bias=sa.out_proj.bias, residual=x)
+            x = ops.layernorm_bf16(x, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+            f = ops.gelu_bf16(ops.gemm(x, w16[pre + "linear1.weight"], bias=layer.linear1.bias))
+            x = ops.gemm(f, w16[pre + "linear2.weight"], bias=layer.linear2.bias, residual=x)
+            x = ops.layernorm_bf16(x, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+        if attention_mask is not None:
+            x = x.view(B, T, D).masked_fill(~attention_mask.bool()[:, :, None], 0.0).view(B * T, D)   # padded rows leave as zeros
+        x = ops.layernorm_bf16(x.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps)
+        y = ops.gemm(x, w16["projection.weight"], bias=self.projection.bias, out_fp32=True)
+        return y.view(B, T, -1)
+
     def forward(self, input_ids, attention_mask, return_pooled=True):
+        if (not return_pooled and input_ids.is_cuda and not (self.training and torch.is_grad_enabled())
+                and not torch.is_grad_enabled() and self.embedding.embedding_dim % 8 == 0
+                and (self.embedding.embedding_dim // self.transformer.layers[0].self_attn.num_heads) % 8 == 0):
+            y = self._forward_hip(input_ids, attention_mask)
+            if y is not None:
+                return y
         x = self.embedding(input_ids)
         pad = ~attention_mask.bool() if attention_mask is not None else None
         for layer in self.transformer.layers:

@@ -93,6 +93,11 @@ int mi355_colsum_bf16(const void* y, float* out, float* scratch, int M, int N, i
  * (image_generator.py:124 passes none).  lse [B][H][Nq] receives log2-domain row statistics. */
 int mi355_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Nq,
                         int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+/* Forward with a key-padding mask (encoder/text_encoder.py:31-34 `src_key_padding_mask=~attention_mask`), given as
+ * the number of valid (leading) keys of each sample: kv_len [B] int32 on the device, 1 <= kv_len[b] <= Nk. */
+int mi355_attention_fwd_masked(const void* q, const void* k, const void* v, void* out, float* lse, const int* kv_len,
+                               int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale,
+                               void* stream);
 int mi355_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                         float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int D, int ldq,
                         int ldk, int ldv, int ldo, float scale, void* stream);
@@ -115,6 +120,7 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
                         float* dgamma_dbeta, float* scratch, int M, int C, void* stream);
 
 /* ---- elementwise / layout -----------------------------------------------------------------------*/
+int mi355_gelu_bf16(const void* in, void* out, long long n, void* stream);                   /* erf GELU (text_encoder.py:22) */
 int mi355_geglu_fwd(const void* in, void* out, long long M, int F, void* stream);           /* in [M][2F] */
 int mi355_geglu_bwd(const void* in, const void* dout, void* din, long long M, int F, void* stream);
 int mi355_silu_f32_to_bf16(const float* x, void* y, long long n, void* stream);

@@ -48,17 +48,26 @@ def main():
     cfg = DenoiserConfig.sd_v1()
     with torch.device(d):
         unet = UNet2DConditionModel(cfg)
-    tr = DenoiserTrainer(unet, lr=1e-4)
     B = 32
-    lat, noise = torch.randn(B, 4, 32, 32, device=d), torch.randn(B, 4, 32, 32, device=d)
+    sampler = len(sys.argv) > 1 and sys.argv[1] == "sampler"      # forward only at 512x512 (latent 64x64)
+    side = 64 if sampler else 32
+    lat, noise = torch.randn(B, 4, side, side, device=d), torch.randn(B, 4, side, side, device=d)
     ctx = torch.randn(B, 77, cfg.cross_attention_dim, device=d).to(BF)
     ts = torch.randint(0, 1000, (B,), device=d)
-    tr.train_step(lat, noise, ts, ctx)
-    ops.gemm, ops.conv2d = rec_gemm, rec_conv
-    tr.train_step(lat, noise, ts, ctx)
+    if sampler:
+        with torch.no_grad():
+            unet(lat, ts, encoder_hidden_states=ctx)
+            ops.gemm, ops.conv2d = rec_gemm, rec_conv
+            unet(lat, ts, encoder_hidden_states=ctx)
+    else:
+        tr = DenoiserTrainer(unet, lr=1e-4)
+        tr.train_step(lat, noise, ts, ctx)
+        ops.gemm, ops.conv2d = rec_gemm, rec_conv
+        tr.train_step(lat, noise, ts, ctx)
+        del tr
     ops.gemm, ops.conv2d = _gemm, _conv
     torch.cuda.synchronize()
-    del tr, unet
+    del unet
     torch.cuda.empty_cache()
 
     rows = []
