@@ -9,6 +9,39 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+// ---- row softmax of a bf16 [M][N] score matrix (single-head attention of the auto-encoder's mid block, whose
+// head dim 512 is beyond the flash kernel): out = softmax(scale * in) per row, one wave per row, fp32 statistics
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int M,
+                                                           int N, float scale_log2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* src = in + (size_t)row * N;
+    bf16_t* dst = out + (size_t)row * N;
+    const int nc = N >> 3;
+    float mx = -INFINITY;
+    for (int c = lane; c < nc; c += 64) {
+        const bf16x8 v = *(const bf16x8*)(src + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[e]);
+    }
+    mx = wave_max(mx) * scale_log2;
+    float sum = 0.f;
+    for (int c = lane; c < nc; c += 64) {
+        const bf16x8 v = *(const bf16x8*)(src + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += exp2f(fmaf((float)v[e], scale_log2, -mx));
+    }
+    const float inv = 1.f / wave_sum(sum);
+    for (int c = lane; c < nc; c += 64) {
+        const bf16x8 v = *(const bf16x8*)(src + c * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(exp2f(fmaf((float)v[e], scale_log2, -mx)) * inv);
+        *(bf16x8*)(dst + c * 8) = o;
+    }
+}
+
 // ---- GELU (erf form), bf16 -> bf16 (text-encoder feed-forward activation)
 __global__ void gelu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, size_t n8) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -515,6 +548,13 @@ extern "C" {
 
 #define ST ((hipStream_t)stream)
 
+int mi355_softmax_rows_bf16(const void* in, void* out, int M, int N, float scale, void* stream) {
+    if (!in || !out || M <= 0 || N <= 0 || (N & 7) || !(scale > 0.f)) return mi355_fail(MI355_ERR_ARG, "softmax_rows: bad arguments (N multiple of 8, scale > 0)");
+    ProfScope prof(FAM_ELEM, ST, (double)M * N * 8);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, M, N,
+                       scale * 1.4426950408889634f);
+    return mi355_check_launch("softmax_rows");
+}
 int mi355_gelu_bf16(const void* in, void* out, long long n, void* stream) {
     if (!in || !out || (n & 7)) return mi355_fail(MI355_ERR_ARG, "gelu: bad arguments (n must be a multiple of 8)");
     ProfScope prof(FAM_ELEM, ST, (double)n * 4);

@@ -23,6 +23,7 @@ struct ConvGeom {
     int ups;          // 1: input is read through a nearest 2x upsample
     int dil;          // 1: input is read through a zero-dilation by 2 (data-gradient of a stride-2 conv)
     int ksize;        // 1 or 3
+    int pad;          // zero padding on the top/left (ksize/2, or 0 for the bottom/right-only padding of the VAE downsampler)
 };
 
 struct GemmArgs {
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const bf16_t* a_base[A_CH];      // dense: row pointer; conv: pointer to pixel (b,0,0,0)
     int a_iy0[A_CH], a_ix0[A_CH];
     bool a_ok[A_CH];
-    const int pad = p.g.ksize >> 1;
+    const int pad = p.g.pad;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int m = m0 + r0 + 32 * i;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     const int kc = (lane & 7) ^ sr;         // k-chunk fetched by this lane (source-side swizzle)
     int a_voff[A_P];                         // dense: byte offset of (row, kc); conv: pixel index of (b,0,0) or -1
     int a_iy0[A_P], a_ix0[A_P];
-    const int pad = p.g.ksize >> 1;
+    const int pad = p.g.pad;
 #pragma unroll
     for (int j = 0; j < A_P; ++j) {
         const int m = m0 + (wave + NW * j) * 8 + sr;
@@ -664,7 +665,7 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
     a.out = out; a.ldo = ldo; a.out_fp32 = out_fp32; a.bias = bias; a.rowbias = rowbias; a.rowbias_div = rowbias_div;
     a.ld_rowbias = ld_rowbias; a.residual = (const bf16_t*)residual; a.ldr = ldr; a.alpha = alpha;
     a.lora_t = lora_t; a.lora_b = lora_b; a.lora_r = lora_r; a.lora_alpha = lora_alpha;
-    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1};
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
     return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -674,7 +675,7 @@ int mi355_gemm_geglu_bf16(const void* A, int lda, const void* Bw, int ldb, int M
     GemmArgs a = {};
     a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = 2 * F; a.K = K; a.lda = lda; a.ldb = ldb;
     a.out = out; a.ldo = ldo; a.out_fp32 = 0; a.bias = bias; a.rowbias_div = 1; a.alpha = 1.f; a.geglu = 1;
-    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1};
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
     return run_gemm(a, AMODE_DENSE, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -701,7 +702,23 @@ int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, 
     a.M = B * Ho * Wo; a.N = Cout; a.K = ksize * ksize * C; a.lda = C; a.ldb = a.K;
     a.out = out; a.ldo = Cout; a.out_fp32 = out_fp32; a.bias = bias; a.rowbias = rowbias; a.rowbias_div = Ho * Wo;
     a.ld_rowbias = ld_rowbias; a.residual = (const bf16_t*)residual; a.ldr = Cout; a.alpha = alpha;
-    a.g = ConvGeom{B, H, W, C, Ho, Wo, stride, ups, dil, ksize};
+    a.g = ConvGeom{B, H, W, C, Ho, Wo, stride, ups, dil, ksize, ksize / 2};
+    const int amode = (C % 64 == 0) ? AMODE_CONV_FAST : AMODE_CONV_GENERIC;
+    return run_gemm(a, amode, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// 3x3 stride-2 convolution whose zero padding is one pixel on the bottom and right only: Ho = H / 2 for even H.
+int mi355_conv2d_down_asym_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, void* out,
+                                const float* bias, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !w || !out) return mi355_fail(MI355_ERR_ARG, "conv2d_down_asym: null pointer");
+    if ((C & 7) || (Cout & 7)) return mi355_fail(MI355_ERR_ARG, "conv2d_down_asym: channels must be multiples of 8");
+    if (H < 2 || W < 2) return mi355_fail(MI355_ERR_ARG, "conv2d_down_asym: input smaller than 2x2");
+    const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
+    GemmArgs a = {};
+    a.A = (const bf16_t*)x; a.Bw = (const bf16_t*)w;
+    a.M = B * Ho * Wo; a.N = Cout; a.K = 9 * C; a.lda = C; a.ldb = a.K;
+    a.out = out; a.ldo = Cout; a.bias = bias; a.rowbias_div = Ho * Wo; a.ldr = Cout; a.alpha = 1.f;
+    a.g = ConvGeom{B, H, W, C, Ho, Wo, 2, 0, 0, 3, 0};
     const int amode = (C % 64 == 0) ? AMODE_CONV_FAST : AMODE_CONV_GENERIC;
     return run_gemm(a, amode, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -379,6 +379,12 @@ static int gn_geometry(int HW, int C, int G, int* threads, int* rpar, int* rows_
     *threads = nc * rp;
     int rows = rp * 8;
     if (rows > HW) rows = HW;
+    // every consumer block re-reduces the strips' group partials in its prologue: keep them few on large maps
+    constexpr int MAX_STRIPS = 32;
+    if ((HW + rows - 1) / rows > MAX_STRIPS) {
+        rows = (HW + MAX_STRIPS - 1) / MAX_STRIPS;
+        rows = (rows + rp - 1) / rp * rp;
+    }
     *rows_per_block = rows;
     *strips = (HW + rows - 1) / rows;
     return 0;

@@ -13,9 +13,9 @@ What differs, and why:
     checkpoint-compatible for the denoiser and for the reference's own TextEncoder);
   * conditioning comes from the repository's `TextEncoder` in its sequence mode
     (encoder/text_encoder.py:41-43, 768-wide = the denoiser's cross-attention width);
-  * `vae` is a fixed (non-learned) 8x8 patch codec with the AutoencoderKL call surface
-    (`encode(x).latent_dist.sample()`, `decode(z).sample`); the learned KL auto-encoder is the next
-    widening step of this path and is not part of the denoiser hot path.
+  * `vae` is the SD-v1 `AutoencoderKL` architecture on the same HIP kernels (vae.py), frozen and
+    inference-only as in the reference (image_generator.py:40), random-initialised until real weights
+    are loaded.
 """
 from __future__ import annotations
 
@@ -29,37 +29,12 @@ from .schedulers import DDIMScheduler, DDPMScheduler
 from .text_encoder import TextEncoder
 from .tokenizer import HashTokenizer, load_tokenizer
 from .unet import DenoiserConfig, UNet2DConditionModel
-
-
-class PatchLatentCodec(nn.Module):
-    """Fixed orthonormal 8x8-patch projection: (B,3,8h,8w) <-> (B,4,h,w).  Stand-in with the
-    AutoencoderKL call surface used at image_generator.py:69,108; frozen, no learned parameters."""
-
-    def __init__(self, latent_channels=4, patch=8, seed=0):
-        super().__init__()
-        g = torch.Generator().manual_seed(seed)
-        q, _ = torch.linalg.qr(torch.randn(3 * patch * patch, 3 * patch * patch, generator=g))
-        self.register_buffer("basis", q[:, :latent_channels].t().contiguous())     # (4, 192)
-        self.patch = patch
-
-    def encode(self, image):
-        p = self.patch
-        b, c, h, w = image.shape
-        x = image.reshape(b, c, h // p, p, w // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b, h // p, w // p, c * p * p)
-        z = (x @ self.basis.t().to(x.dtype)).permute(0, 3, 1, 2).contiguous() * (p * 0.75)
-        return SimpleNamespace(latent_dist=SimpleNamespace(sample=lambda: z))
-
-    def decode(self, latents):
-        p = self.patch
-        b, c, h, w = latents.shape
-        x = (latents.permute(0, 2, 3, 1) / (p * 0.75)) @ self.basis.to(latents.dtype)
-        x = x.reshape(b, h, w, 3, p, p).permute(0, 3, 1, 4, 2, 5).reshape(b, 3, h * p, w * p)
-        return SimpleNamespace(sample=x)
+from .vae import AutoencoderKL, VaeConfig
 
 
 class ImageGenerator(nn.Module):
     def __init__(self, device, tokenizer_path=None, unet_config: DenoiserConfig | None = None,
-                 text_encoder_kwargs: dict | None = None):
+                 text_encoder_kwargs: dict | None = None, vae_config: VaeConfig | None = None):
         super().__init__()
         self.device = device
         self.dtype = torch.float32
@@ -69,7 +44,9 @@ class ImageGenerator(nn.Module):
         te_kwargs.setdefault("projection_dim", cfg.cross_attention_dim)
         self.text_encoder = TextEncoder(**te_kwargs).to(self.device)
         self.unet = UNet2DConditionModel(cfg).to(self.device).to(self.dtype)
-        self.vae = PatchLatentCodec(cfg.in_channels).to(self.device).to(self.dtype)
+        if vae_config is None:        # the SD-v1 auto-encoder next to the SD-v1 denoiser, a small one next to a test-size denoiser
+            vae_config = VaeConfig.sd_v1() if unet_config is None else VaeConfig.small()
+        self.vae = AutoencoderKL(vae_config).to(self.device).to(self.dtype)
         self.scheduler = DDPMScheduler()
         self.infer_scheduler = DDIMScheduler()
         self.text_encoder.requires_grad_(False)
@@ -94,7 +71,7 @@ class ImageGenerator(nn.Module):
 
     # image_generator.py:63-71
     def decode_latents(self, latents):
-        vae_device = self.vae.basis.device
+        vae_device = next(self.vae.parameters()).device
         latents = 1 / 0.18215 * latents.to(vae_device)
         with torch.no_grad():
             image = self.vae.decode(latents).sample

@@ -53,6 +53,11 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
                     const void* residual, int ldr, float alpha, const float* lora_t, const float* lora_b, int lora_r,
                     float lora_alpha, void* workspace, size_t workspace_bytes, void* stream);
 
+/* 3x3 stride-2 convolution with one pixel of zero padding on the bottom and right only (the AutoencoderKL
+ * down-sampler reached through image_generator.py:107-108 `self.vae.encode`): x [B][H][W][C] -> out [B][H/2][W/2][Cout]. */
+int mi355_conv2d_down_asym_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, void* out,
+                                const float* bias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* GEGLU feed-forward input projection with the gate in the epilogue (inference path of the transformer block's
  * `ff.net[0]`, reached through image_generator.py:93-95): Bw [2F][K] = hidden rows then gate rows, bias [2F] or
  * NULL, out[M][F] = (A.Bw_h^T + b_h) * gelu_erf(A.Bw_g^T + b_g).  F a multiple of 80, K of 64. */
@@ -120,6 +125,8 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
                         float* dgamma_dbeta, float* scratch, int M, int C, void* stream);
 
 /* ---- elementwise / layout -----------------------------------------------------------------------*/
+/* out[m][:] = softmax(scale * in[m][:]) over bf16 rows (single-head attention of the auto-encoder mid block) */
+int mi355_softmax_rows_bf16(const void* in, void* out, int M, int N, float scale, void* stream);
 int mi355_gelu_bf16(const void* in, void* out, long long n, void* stream);                   /* erf GELU (text_encoder.py:22) */
 int mi355_geglu_fwd(const void* in, void* out, long long M, int F, void* stream);           /* in [M][2F] */
 int mi355_geglu_bwd(const void* in, const void* dout, void* din, long long M, int F, void* stream);

@@ -100,3 +100,24 @@ def test_denoiser_oracle_structure():
     xt = ops_ref.ddpm_add_noise(x0, eps, torch.tensor([481]), acp)
     prev = ops_ref.ddim_step(eps, 481, xt, acp, 50)             # with the true noise DDIM lands on the t-20 marginal
     assert torch.allclose(prev, ops_ref.ddpm_add_noise(x0, eps, torch.tensor([461]), acp), atol=1e-5)
+
+
+def test_vae_oracle_parameter_count_and_shapes():
+    """The auto-encoder restatement has the public SD-v1 checkpoint's parameter count and names (its only external
+    pin: parity with the third-party package is unpinned), and the bottom/right-padded down-samplers halve sizes."""
+    from oracle.vae_ref import AutoencoderKLRef, VaeConfig, count_params
+    with torch.device("meta"):
+        full = AutoencoderKLRef(VaeConfig.sd_v1())
+    assert count_params(full) == 83_653_863
+    keys = set(full.state_dict())
+    for k in ("encoder.down_blocks.0.downsamplers.0.conv.weight", "encoder.mid_block.attentions.0.to_q.bias",
+              "decoder.up_blocks.3.resnets.2.conv2.weight", "decoder.up_blocks.2.upsamplers.0.conv.bias",
+              "quant_conv.weight", "post_quant_conv.bias", "decoder.mid_block.attentions.0.to_out.0.weight"):
+        assert k in keys, k
+    torch.manual_seed(0)
+    small = AutoencoderKLRef(VaeConfig.small()).eval()
+    x = torch.rand(1, 3, 32, 48) * 2 - 1
+    with torch.no_grad():
+        d = small.encode(x).latent_dist
+        assert d.mean.shape == (1, 4, 4, 6) and float(d.logvar.max()) <= 20.0
+        assert small.decode(d.mode()).sample.shape == x.shape
