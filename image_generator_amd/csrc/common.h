@@ -70,6 +70,15 @@ static __global__ void zero_fill_kernel(char* __restrict__ p, size_t bytes) {
         *(f32x4*)(p + (i << 4)) = z;
     if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) p[(n16 << 4) + threadIdx.x] = 0;
 }
+// Zero many ranges in one launch: table[2i] = device address (16-byte aligned), table[2i+1] = bytes (multiple of 16).
+// grid = (blocks per range, ranges).
+static __global__ void zero_ranges_kernel(const long long* __restrict__ table) {
+    char* p = (char*)table[2 * blockIdx.y];
+    const size_t n16 = (size_t)table[2 * blockIdx.y + 1] >> 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        *(f32x4*)(p + (i << 4)) = z;
+}
 // p must be 16-byte aligned (every buffer of this library is).
 static inline void mi355_zero_async(void* p, size_t bytes, hipStream_t st) {
     if (bytes == 0) return;

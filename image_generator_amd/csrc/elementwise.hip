@@ -666,6 +666,11 @@ int mi355_zero_f32(float* p, long long n, void* stream) {
     mi355_zero_async(p, (size_t)n * sizeof(float), ST);
     return mi355_check_launch("zero");
 }
+int mi355_zero_ranges(const long long* table, int n, void* stream) {
+    if (!table || n <= 0) return mi355_fail(MI355_ERR_ARG, "zero_ranges: bad arguments");
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(64, n), dim3(256), 0, ST, table);
+    return mi355_check_launch("zero_ranges");
+}
 int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
                      long long n, void* stream) {
     if (!p || !g || !m || !v || !hyper || !state) return mi355_fail(MI355_ERR_ARG, "adamw: null pointer");

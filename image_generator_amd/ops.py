@@ -131,7 +131,7 @@ class WgradQueue:
         self._inflight = []
         self.jb = int(lib.mi355_wgrad_job_bytes())
         self.max_jobs, self.flush_blocks = max_jobs, flush_blocks
-        self._ring = [torch.empty(max_jobs * self.jb, dtype=torch.uint8).pin_memory() for _ in range(ring)]
+        self._ring = [torch.empty(max_jobs * (self.jb + 16), dtype=torch.uint8).pin_memory() for _ in range(ring)]
         self._ri = 0
         self._ring_size = ring
         self._keep = []          # pinned tables referenced by captured graphs (must outlive them)
@@ -142,12 +142,18 @@ class WgradQueue:
         self._refs = []
         self._cbs = []
         self._splits = ctypes.c_int(0)
+        # destinations of pixel-split jobs accumulate with atomics: the queue zeroes exactly those (one launch per
+        # flush) when `zero_split_outputs` is set, so the owner need not clear the whole gradient buffer every step
+        self.zero_split_outputs = False
+        self._zero = []
 
     def push(self, dy, x, dw, dbias, B, H, W, cin, cout, ksize, stride, ups, Ho, Wo, callback=None):
         nb = lib.mi355_wgrad_job_fill(self._host.data_ptr() + self._n * self.jb, dy.data_ptr(), x.data_ptr(),
                                       dw.data_ptr(), _ptr(dbias), B, H, W, cin, cout, ksize, stride, int(ups), Ho, Wo,
                                       self._blocks, ctypes.byref(self._splits))
         check(min(nb, 0), "wgrad_job_fill")
+        if self.zero_split_outputs and self._splits.value > 1:
+            self._zero.append((dw.data_ptr(), dw.numel() * 4))
         self._n += 1
         self._blocks += nb
         self._flops += 2.0 * B * Ho * Wo * cout * ksize * ksize * cin
@@ -163,8 +169,15 @@ class WgradQueue:
         nbytes = self._n * self.jb
 
         def launch():
-            table = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            table.copy_(self._host[:nbytes], non_blocking=True)
+            nz = len(self._zero)
+            table = torch.empty(nbytes + 16 * nz, dtype=torch.uint8, device=self.device)
+            if nz:
+                zt = self._host[nbytes:nbytes + 16 * nz].view(torch.int64)
+                for i, (ptr, nb) in enumerate(self._zero):
+                    zt[2 * i], zt[2 * i + 1] = ptr, nb
+            table.copy_(self._host[:nbytes + 16 * nz], non_blocking=True)
+            if nz:
+                check(lib.mi355_zero_ranges(table.data_ptr() + nbytes, nz, _stream()), "zero_ranges")
             check(lib.mi355_wgrad_grouped(table.data_ptr(), self._n, self._blocks, self._flops, _stream()), "wgrad_grouped")
             return table
 
@@ -185,11 +198,11 @@ class WgradQueue:
             self._ri %= len(self._ring)
         else:
             while len(self._ring) < self._ring_size:
-                self._ring.append(torch.empty(self.max_jobs * self.jb, dtype=torch.uint8).pin_memory())
+                self._ring.append(torch.empty(self.max_jobs * (self.jb + 16), dtype=torch.uint8).pin_memory())
             self._ri = (self._ri + 1) % len(self._ring)
         self._host = self._ring[self._ri]
         self._n, self._blocks, self._flops = 0, 0, 0.0
-        self._refs, self._cbs = [], []
+        self._refs, self._cbs, self._zero = [], [], []
 
     def join(self):
         """Flush, then make the current stream wait for every grouped launch issued so far."""

@@ -237,13 +237,16 @@ class DenoiserTrainer:
         # side stream measured 45.3 ms/step against 40.0 (their long workgroups starve the dependent chain).
         side = self.reducer is None and os.environ.get("MI355_WGRAD_SIDE") == "1"
         self.wgrad_queue = _ops.WgradQueue(dev, side_stream=side) if os.environ.get("MI355_NO_WGRAD_QUEUE") != "1" else None
+        if self.wgrad_queue is not None:
+            self.wgrad_queue.zero_split_outputs = True
 
     def forward_backward(self, latents, noise, t, ctx):
         B = latents.shape[0]
         noisy = torch.empty_like(latents)
         check(lib.mi355_ddpm_add_noise(latents.data_ptr(), noise.data_ptr(), t.data_ptr(), self.acp.data_ptr(),
                                        noisy.data_ptr(), B, latents[0].numel(), _stream()), "ddpm_add_noise")
-        self.unet.zero_small_grads()
+        # with the queue, pixel-split weight gradients are cleared per job and unsplit ones are plain stores
+        self.unet.zero_small_grads(weights_too=self.wgrad_queue is None)
         pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
         loss = mse_loss(pred, noise)
         self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched

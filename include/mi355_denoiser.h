@@ -164,6 +164,8 @@ int mi355_ddim_step_cfg(const float* eps, const float* x, float* out, const floa
  * grad pre-scale.  state (device floats): [0] = sum of squared gradients.  Non-finite norm skips. */
 int mi355_sumsq_f32(const float* g, float* out, long long n, void* stream);
 int mi355_zero_f32(float* p, long long n, void* stream);
+/* Zero n ranges in one launch: table (device, int64 pairs) = address (16-byte aligned), bytes (multiple of 16). */
+int mi355_zero_ranges(const long long* table, int n, void* stream);
 int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
                      long long n, void* stream);
 
