@@ -479,68 +479,132 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
         }
     }
 }
-// dt[m][r] = alpha * sum_n dy[m][n] * Bm[n][r]   (dy bf16 [M][N], Bm fp32 [N][R])
+// dt[m][r] = alpha * sum_n dy[m][n] * Bm[n][r]   (dy bf16 [M][N], Bm fp32 [N][R]); one wave per row.
+// R4: rank 4, each column's four factors are one 16-byte load.
+template <bool R4>
 __global__ __launch_bounds__(256) void lora_dt_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ Bm,
                                                       float* __restrict__ dt, int M, int N, int R, float alpha) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    float acc[16];
+    constexpr int RA = R4 ? 4 : 16;
+    float acc[RA];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < RA; ++r) acc[r] = 0.f;
     for (int n = lane * 8; n < N; n += 512) {
         const bf16x8 dv = *(const bf16x8*)(dy + (size_t)row * N + n);
+        if (R4) {
+            const f32x4* bp = (const f32x4*)(Bm + (size_t)n * 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float d = (float)dv[e];
+            for (int e = 0; e < 8; ++e) {
+                const f32x4 bv = bp[e];
+                const float d = (float)dv[e];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (r < R) acc[r] += d * Bm[(size_t)(n + e) * R + r];
+                for (int r = 0; r < 4; ++r) acc[r] += d * bv[r];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)dv[e];
+#pragma unroll
+                for (int r = 0; r < RA; ++r)
+                    if (r < R) acc[r] += d * Bm[(size_t)(n + e) * R + r];
+            }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < RA; ++r) {
         if (r < R) {
             const float s = wave_sum(acc[r]);
             if (lane == 0) dt[(size_t)row * R + r] = s * alpha;
         }
     }
 }
-// out[c][r] (+)= scale * sum_m y[m][c] * t[m][r]   (y bf16 [M][C], t fp32 [M][R]); out fp32 [C][R] pre-zeroed.
-// Serves dB (y = dy, t = x A^T, scale = alpha) and dA^T (y = x, t = dt, scale = 1).
+// out[c][r] += scale * sum_m y[m][c] * t[m][r]   (y bf16 [M][C], t fp32 [M][R]); out fp32 [C][R] (or [R][C] when
+// `transposed`), zeroed beforehand.  Serves dB (y = dy, t = x A^T, scale = alpha) and dA (y = x, t = dt, scale = 1).
+// A workgroup is NC = C/8 column chunks x RL row lanes; it walks `rows_per_block` rows, combines the row lanes
+// through LDS and adds its [C][R] partial to the result with atomics.  Hundreds of workgroups adding to the same
+// few thousand addresses serialise in L2 (measured ~100 us per call), so the caller may offer `slices` copies of
+// the result `slice_stride` floats apart: workgroup b adds to copy b % slices and the caller sums the copies.
+template <bool R4>
 __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restrict__ y, const float* __restrict__ t,
                                                          float* __restrict__ out, int M, int C, int R, float scale,
-                                                         int rows_per_block, int out_transposed) {
-    const int nc = C >> 3;
-    const int r_begin = blockIdx.x * rows_per_block;
-    int r_end = r_begin + rows_per_block;
-    if (r_end > M) r_end = M;
-    for (int c8 = threadIdx.x; c8 < nc; c8 += blockDim.x) {
-        float acc[8][16];
+                                                         int rows_per_block, int NC, int RL, int transposed,
+                                                         int slices, long long slice_stride) {
+    constexpr int RA = R4 ? 4 : 16;
+    out += (size_t)(blockIdx.x % slices) * slice_stride;
+    extern __shared__ float red[];          // [RL-1][NC][8*RA] partials of row lanes 1..RL-1
+    const int tid = threadIdx.x;
+    const int c8 = tid % NC, rl = tid / NC;
+    const int c0 = blockIdx.y * NC * 8 + c8 * 8;
+    const bool active = rl < RL && c0 < C;
+    const int m_begin = blockIdx.x * rows_per_block;
+    const int m_end = min(M, m_begin + rows_per_block);
+    float acc[8][RA];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-        for (int m = r_begin; m < r_end; ++m) {
-            const bf16x8 yv = *(const bf16x8*)(y + (size_t)m * C + c8 * 8);
+        for (int r = 0; r < RA; ++r) acc[e][r] = 0.f;
+    if (active) {
+        int m = m_begin + rl;
+        for (; m + RL < m_end; m += 2 * RL) {        // two rows in flight
+            const bf16x8 y0 = *(const bf16x8*)(y + (size_t)m * C + c0);
+            const bf16x8 y1 = *(const bf16x8*)(y + (size_t)(m + RL) * C + c0);
+            if (R4) {
+                const f32x4 t0 = *(const f32x4*)(t + (size_t)m * 4), t1 = *(const f32x4*)(t + (size_t)(m + RL) * 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r < R) {
-                    const float tv = t[(size_t)m * R + r];
+                for (int e = 0; e < 8; ++e)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e][r] += (float)yv[e] * tv;
-                }
+                    for (int r = 0; r < 4; ++r) acc[e][r] += (float)y0[e] * t0[r] + (float)y1[e] * t1[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < RA; ++r)
+                    if (r < R) {
+                        const float t0 = t[(size_t)m * R + r], t1 = t[(size_t)(m + RL) * R + r];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e][r] += (float)y0[e] * t0 + (float)y1[e] * t1;
+                    }
             }
         }
+        for (; m < m_end; m += RL) {
+            const bf16x8 y0 = *(const bf16x8*)(y + (size_t)m * C + c0);
+#pragma unroll
+            for (int r = 0; r < RA; ++r)
+                if (r < R) {
+                    const float t0 = t[(size_t)m * R + r];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e][r] += (float)y0[e] * t0;
+                }
+        }
+    }
+    if (RL > 1) {
+        if (active && rl > 0) {
+            float* dst = red + ((size_t)(rl - 1) * NC + c8) * (8 * RA);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int r = 0; r < RA; ++r) dst[e * RA + r] = acc[e][r];
+        }
+        __syncthreads();
+        if (active && rl == 0) {
+            for (int j = 0; j < RL - 1; ++j) {
+                const float* src = red + ((size_t)j * NC + c8) * (8 * RA);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int r = 0; r < RA; ++r) acc[e][r] += src[e * RA + r];
+            }
+        }
+    }
+    if (active && rl == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < RA; ++r)
                 if (r < R) {
-                    float* dst = out_transposed ? out + (size_t)r * C + c8 * 8 + e : out + (size_t)(c8 * 8 + e) * R + r;
+                    float* dst = transposed ? out + (size_t)r * C + c0 + e : out + (size_t)(c0 + e) * R + r;
                     atomicAdd(dst, acc[e][r] * scale);
                 }
-            }
     }
 }
 
@@ -715,16 +779,41 @@ int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R
 }
 int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* stream) {
     if (!dy || !Bm || !dt || (N & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_dt: bad arguments");
-    hipLaunchKernelGGL(lora_dt_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha);
+    if (R == 4) hipLaunchKernelGGL(lora_dt_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha);
+    else hipLaunchKernelGGL(lora_dt_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha);
     return mi355_check_launch("lora_dt");
 }
-int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int out_transposed,
-                     void* stream) {
-    if (!y || !t || !out || (C & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_outer: bad arguments");
-    mi355_zero_async(out, (size_t)C * R * sizeof(float), ST);
-    const int rows = 128;
-    hipLaunchKernelGGL(lora_outer_kernel, dim3((M + rows - 1) / rows), dim3(128), 0, ST, (const bf16_t*)y, t, out, M, C, R, scale, rows, out_transposed);
+// flags: bit 0 = result laid out [R][C] instead of [C][R]; bit 1 = accumulate into `out` (the caller zeroed it, or
+// wants the sum with its previous contents) instead of overwriting it
+int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int flags,
+                     int slices, long long slice_stride, void* stream) {
+    if (!y || !t || !out || (C & 7) || R < 1 || R > 16 || M < 1 || slices < 1 || (slices > 1 && !(flags & 2)))
+        return mi355_fail(MI355_ERR_ARG, "lora_outer: bad arguments");
+    if (!(flags & 2)) mi355_zero_async(out, (size_t)C * R * sizeof(float), ST);
+    const int nc_all = C / 8;
+    const int NC = nc_all < 256 ? nc_all : 256;               // column chunks per workgroup
+    const int RA = R == 4 ? 4 : 16;
+    int RL = 256 / NC;                                         // row lanes, as many as 48 KB of LDS partials allow
+    const int rl_cap = 1 + (48 * 1024) / (NC * 8 * RA * (int)sizeof(float));
+    if (RL > rl_cap) RL = rl_cap;
+    const int gy = (nc_all + NC - 1) / NC;
+    int rows = (M + 255) / 256;                                // ~256 workgroups, at least 8 rows per row lane
+    if (rows < 8 * RL) rows = 8 * RL;
+    const int gx = (M + rows - 1) / rows;
+    const size_t smem = (size_t)(RL - 1) * NC * 8 * RA * sizeof(float);
+    if (R == 4)
+        hipLaunchKernelGGL(lora_outer_kernel<true>, dim3(gx, gy), dim3(256), smem, ST, (const bf16_t*)y, t, out, M, C, R, scale,
+                           rows, NC, RL, flags & 1, slices, slice_stride);
+    else
+        hipLaunchKernelGGL(lora_outer_kernel<false>, dim3(gx, gy), dim3(256), smem, ST, (const bf16_t*)y, t, out, M, C, R, scale,
+                           rows, NC, RL, flags & 1, slices, slice_stride);
     return mi355_check_launch("lora_outer");
+}
+// out[n] = sum_r partial[r][n]   (fp32, N a multiple of 4)
+int mi355_sum_rows_f32(const float* partial, float* out, int R, long long N, void* stream) {
+    if (!partial || !out || R < 1 || N < 4 || (N & 3) || N > 0x7fffffffLL) return mi355_fail(MI355_ERR_ARG, "sum_rows: bad arguments");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64), 1), dim3(256), 0, ST, partial, out, R, (int)N, (float*)nullptr, 0);
+    return mi355_check_launch("sum_rows");
 }
 
 }  // extern "C"

@@ -43,6 +43,9 @@ struct GemmArgs {
     const float* lora_t;     // [M][lora_r] fp32 or null  (x A^T)
     const float* lora_b;     // [N][lora_r] fp32          (B)
     int lora_r;
+    int lora_ldt;            // row stride of lora_t (floats)
+    int lora_seg;            // > 0: outputs per row-stacked adapter (each reads its own r columns of lora_t)
+    int lora_rmajor;         // lora_b is [r][N] instead of [N][r]
     float lora_alpha;
     float* partial;          // split-K slabs [splitk][M][N] fp32
     int splitk, kt_per_split;
@@ -56,6 +59,35 @@ enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2 };
 __device__ __forceinline__ float gemm_gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 // Shared tail of both GEMM kernels: split-K slab store, or the LDS-staged vectorised epilogue.
+// Low-rank term of 8 adjacent outputs: v[e] += lora_alpha * sum_r t[m][r] * b(n + e, r).  `lora_seg` > 0: the columns
+// are row-stacked adapters of `lora_seg` outputs each and adapter s reads t[m][s*r .. s*r + r) (fused projections).
+__device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, float (&v)[8]) {
+    const float* t = p.lora_t + (size_t)m * p.lora_ldt + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
+    if (p.lora_rmajor) {                        // factors [r][N]: eight adjacent columns are two 16-byte loads per rank
+        for (int r = 0; r < p.lora_r; ++r) {
+            const float tv = t[r] * p.lora_alpha;
+            const float* bp = p.lora_b + (size_t)r * p.N + n;
+            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += tv * b0[e]; v[4 + e] += tv * b1[e]; }
+        }
+    } else if (p.lora_r == 4) {                 // factors [N][4]: one 16-byte load per column
+        const f32x4 tv = *(const f32x4*)t * p.lora_alpha;
+        const f32x4* bp = (const f32x4*)(p.lora_b + (size_t)n * 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const f32x4 bv = bp[e];
+            v[e] += tv[0] * bv[0] + tv[1] * bv[1] + tv[2] * bv[2] + tv[3] * bv[3];
+        }
+    } else {
+        for (int r = 0; r < p.lora_r; ++r) {
+            const float tv = t[r] * p.lora_alpha;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += tv * p.lora_b[(size_t)(n + e) * p.lora_r + r];
+        }
+    }
+}
+
 template <int BN, int TM, int TN, int NTHREADS = 256>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], char* smem, int m0, int n0,
                                               int split, int wm0, int wn0, int wave, int tid, int fr, int fq) {
@@ -128,14 +160,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rb[e];
             }
-            if (p.lora_t) {
-                const float* t = p.lora_t + (size_t)m * p.lora_r;
-                for (int r = 0; r < p.lora_r; ++r) {
-                    const float tv = t[r] * p.lora_alpha;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += tv * p.lora_b[(size_t)(n + e) * p.lora_r + r];
-                }
-            }
+            if (p.lora_t) lora_apply(p, m, n, v);
             if (p.residual) {
                 const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
@@ -499,14 +524,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rb[e];
         }
-        if (p.lora_t) {
-            const float* t = p.lora_t + (size_t)m * p.lora_r;
-            for (int r = 0; r < p.lora_r; ++r) {
-                const float tv = t[r] * p.lora_alpha;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += tv * p.lora_b[(size_t)(n + e) * p.lora_r + r];
-            }
-        }
+        if (p.lora_t) lora_apply(p, m, n, v);
         if (p.residual) {
             const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
@@ -657,14 +675,18 @@ size_t mi355_gemm_workspace_bytes(int M, int N) {
 
 int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
                     int out_fp32, const float* bias, const float* rowbias, int rowbias_div, int ld_rowbias,
-                    const void* residual, int ldr, float alpha, const float* lora_t, const float* lora_b, int lora_r,
-                    float lora_alpha, void* workspace, size_t workspace_bytes, void* stream) {
+                    const void* residual, int ldr, float alpha, const float* lora_t, int lora_ldt, const float* lora_b, int lora_r,
+                    int lora_seg, int lora_rmajor, float lora_alpha, void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !Bw || !out) return mi355_fail(MI355_ERR_ARG, "gemm: null pointer");
+    if (lora_t && (!lora_b || lora_r < 1 || lora_ldt < lora_r || (lora_seg && (lora_seg & 7)) ||
+                   ((lora_r == 4 && !lora_rmajor) && (lora_ldt & 3))))
+        return mi355_fail(MI355_ERR_ARG, "gemm: bad low-rank operands (r=%d ldt=%d seg=%d)", lora_r, lora_ldt, lora_seg);
     GemmArgs a = {};
     a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
     a.out = out; a.ldo = ldo; a.out_fp32 = out_fp32; a.bias = bias; a.rowbias = rowbias; a.rowbias_div = rowbias_div;
     a.ld_rowbias = ld_rowbias; a.residual = (const bf16_t*)residual; a.ldr = ldr; a.alpha = alpha;
     a.lora_t = lora_t; a.lora_b = lora_b; a.lora_r = lora_r; a.lora_alpha = lora_alpha;
+    a.lora_ldt = lora_ldt; a.lora_seg = lora_seg; a.lora_rmajor = lora_rmajor;
     a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
     return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
 }

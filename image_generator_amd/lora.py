@@ -33,41 +33,73 @@ def _operands(original):
     return cache[1], cache[2]
 
 
+def _f32c(p):
+    p = p.detach()
+    return p if (p.dtype == F32 and p.is_contiguous()) else p.to(F32).contiguous()
+
+
 class _LoraLinearFn(torch.autograd.Function):
+    """y = x W^T + b + alpha * (x A^T) B^T (+ residual).  `gdst` = (dA, dB, slices, stride): fp32 views into the first
+    of `slices` zeroed copies (stride floats apart) of a flat gradient buffer; the adapter gradients are accumulated
+    over the copies and their owner sums them once per step.  Without it they are returned to autograd."""
+
     @staticmethod
-    def forward(ctx, x, a, b, bias, alpha, w16, w16_t):
+    def forward(ctx, x, a, b, bias, alpha, w16, w16_t, residual, gdst):
         if not x.is_cuda:
             raise RuntimeError("LoRALinear: HIP device tensors required (no CPU path)")
         K = x.shape[-1]
-        x2 = x.reshape(-1, K).to(BF16).contiguous()
+        x2 = x.reshape(-1, K)
+        if x2.dtype != BF16 or not x2.is_contiguous():
+            x2 = x2.to(BF16).contiguous()
         M, r, N = x2.shape[0], a.shape[0], b.shape[0]
-        af, bf = a.detach().to(F32).contiguous(), b.detach().to(F32).contiguous()
+        af, bf = _f32c(a), _f32c(b)
         t = torch.empty((M, r), dtype=F32, device=x.device)
         check(lib.mi355_lora_down(x2.data_ptr(), af.data_ptr(), t.data_ptr(), M, K, r, _stream()), "lora_down")
-        biasf = None if bias is None else bias.detach().to(F32).contiguous()
-        y = gemm(x2, w16, bias=biasf, lora_t=t, lora_b=bf, lora_alpha=alpha)
+        biasf = None if bias is None else _f32c(bias)
+        res2 = None if residual is None else residual.reshape(-1, N)
+        y = gemm(x2, w16, bias=biasf, residual=res2, lora_t=t, lora_b=bf, lora_alpha=alpha)
         ctx.save_for_backward(x2, t, af, bf)
-        ctx.alpha, ctx.w16_t, ctx.xshape, ctx.xdtype = alpha, w16_t, x.shape, x.dtype
-        return y.view(*x.shape[:-1], N).to(x.dtype)
+        ctx.alpha, ctx.w16_t, ctx.xshape, ctx.xdtype, ctx.gdst = alpha, w16_t, x.shape, x.dtype, gdst
+        y = y.view(*x.shape[:-1], N)
+        return y if x.dtype == BF16 else y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, dy):
         x2, t, af, bf = ctx.saved_tensors
         M, K = x2.shape
         N, r = bf.shape
-        dy2 = dy.reshape(-1, N).to(BF16).contiguous()
+        dy2 = dy.reshape(-1, N)
+        if dy2.dtype != BF16 or not dy2.is_contiguous():
+            dy2 = dy2.to(BF16).contiguous()
+        s = _stream()
         dt = torch.empty((M, r), dtype=F32, device=dy.device)
-        check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, ctx.alpha, _stream()), "lora_dt")
-        db = torch.empty((N, r), dtype=F32, device=dy.device)
-        check(lib.mi355_lora_outer(dy2.data_ptr(), t.data_ptr(), db.data_ptr(), M, N, r, ctx.alpha, 0, _stream()), "lora_outer")
-        da = torch.empty((r, K), dtype=F32, device=dy.device)
-        check(lib.mi355_lora_outer(x2.data_ptr(), dt.data_ptr(), da.data_ptr(), M, K, r, 1.0, 1, _stream()), "lora_outer")
+        check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, ctx.alpha, s), "lora_dt")
+        da = db = None
+        want_a, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if ctx.gdst is not None:
+            ga, gb, slices, stride = ctx.gdst
+            if want_b:
+                check(lib.mi355_lora_outer(dy2.data_ptr(), t.data_ptr(), gb.data_ptr(), M, N, r, ctx.alpha, 2, slices, stride, s),
+                      "lora_outer")
+            if want_a:
+                check(lib.mi355_lora_outer(x2.data_ptr(), dt.data_ptr(), ga.data_ptr(), M, K, r, 1.0, 3, slices, stride, s),
+                      "lora_outer")
+        else:
+            if want_b:
+                db = torch.empty((N, r), dtype=F32, device=dy.device)
+                check(lib.mi355_lora_outer(dy2.data_ptr(), t.data_ptr(), db.data_ptr(), M, N, r, ctx.alpha, 0, 1, 0, s), "lora_outer")
+            if want_a:
+                da = torch.empty((r, K), dtype=F32, device=dy.device)
+                check(lib.mi355_lora_outer(x2.data_ptr(), dt.data_ptr(), da.data_ptr(), M, K, r, 1.0, 1, 1, 0, s), "lora_outer")
         dx = None
         if ctx.needs_input_grad[0]:
-            # dx = dy W + dt A : the rank-r term rides in the epilogue of the data-gradient GEMM
-            dx = gemm(dy2, ctx.w16_t, lora_t=dt, lora_b=af.t().contiguous(), lora_alpha=1.0)
-            dx = dx.view(ctx.xshape).to(ctx.xdtype)
-        return dx, da, db, None, None, None, None
+            # dx = dy W + dt A : the rank-r term rides in the epilogue of the data-gradient GEMM (A as stored, [r][K])
+            dx = gemm(dy2, ctx.w16_t, lora_t=dt, lora_b=af, lora_alpha=1.0, lora_rmajor=True)
+            dx = dx.view(ctx.xshape)
+            if ctx.xdtype != BF16:
+                dx = dx.to(ctx.xdtype)
+        dres = dy if ctx.needs_input_grad[7] else None
+        return dx, da, db, None, None, None, None, dres, None
 
 
 class LoRALinear(nn.Module):
@@ -83,10 +115,13 @@ class LoRALinear(nn.Module):
         nn.init.zeros_(self.lora_B.weight)
         for p in self.original.parameters():
             p.requires_grad = False
+        self.grad_dst = None        # (dA, dB, slices, stride) into a sliced flat gradient buffer in direct-gradient mode
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """`residual` (optional, beyond the reference signature) is added in the same GEMM epilogue."""
         w16, w16_t = _operands(self.original)
-        return _LoraLinearFn.apply(x, self.lora_A.weight, self.lora_B.weight, self.original.bias, self.alpha, w16, w16_t)
+        return _LoraLinearFn.apply(x, self.lora_A.weight, self.lora_B.weight, self.original.bias, self.alpha, w16, w16_t,
+                                   residual, self.grad_dst)
 
 
 def extract_lora_weights(model):

@@ -52,8 +52,9 @@ def _req(t, dtype, name):
 # raw calls
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=False, alpha=1.0,
-         lora_t=None, lora_b=None, lora_alpha=0.0, out=None):
-    """out[M,N] = alpha * a[M,K] @ w[N,K]^T (+ bias + rowbias + lora + residual).  a may have a row stride."""
+         lora_t=None, lora_b=None, lora_alpha=0.0, out=None, lora_seg=0, lora_rmajor=False):
+    """out[M,N] = alpha * a[M,K] @ w[N,K]^T (+ bias + rowbias + lora + residual).  a may have a row stride.
+    lora_t [M, r] (or [M, S*r] with lora_seg = N/S for S row-stacked adapters), lora_b [N, r] (or [r, N] if lora_rmajor)."""
     assert a.dtype == BF16 and w.dtype == BF16 and a.is_cuda
     M, K = a.shape
     N = w.shape[0]
@@ -61,12 +62,17 @@ def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=F
     if out is None:
         out = torch.empty((M, N), dtype=F32 if out_fp32 else BF16, device=a.device)
     ws = workspace(a.device)
-    r = 0 if lora_t is None else lora_t.shape[1]
+    r = ldt = 0
+    if lora_t is not None:
+        assert lora_t.dtype == F32 and lora_b.dtype == F32 and lora_t.is_contiguous() and lora_b.is_contiguous()
+        r = lora_b.shape[0] if lora_rmajor else lora_b.shape[1]
+        ldt = lora_t.shape[1]
+        assert lora_t.shape[0] == M and lora_b.numel() == N * r and ldt == (r * (N // lora_seg) if lora_seg else r)
     check(lib.mi355_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), K, M, N, K, out.data_ptr(), out.stride(0),
                               1 if out.dtype == F32 else 0, _ptr(bias), _ptr(rowbias), rowbias_div,
                               0 if rowbias is None else rowbias.stride(0), _ptr(residual),
-                              0 if residual is None else residual.stride(0), alpha, _ptr(lora_t), _ptr(lora_b), r,
-                              lora_alpha, ws.data_ptr(), ws.numel(), _stream()), "gemm")
+                              0 if residual is None else residual.stride(0), alpha, _ptr(lora_t), ldt, _ptr(lora_b), r,
+                              lora_seg, int(lora_rmajor), lora_alpha, ws.data_ptr(), ws.numel(), _stream()), "gemm")
     return out
 
 

@@ -129,8 +129,13 @@ class FusedAdamW:
 
     def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0):
         self.unet = unet
-        self.flat, self.flat16 = unet.flat_parameters()
+        flat, flat16 = unet.flat_parameters()
+        # everything, or (frozen base + LoRA adapters) the adapters' contiguous tail of the flat storage
+        self.base, end = unet.trainable_range()
+        self.frozen_base = self.base != 0
+        self.flat, self.flat16 = flat[self.base:end], flat16[self.base:end]
         self.grad = unet.enable_direct_grads()
+        assert self.grad.numel() == self.flat.numel()
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
@@ -159,7 +164,8 @@ class FusedAdamW:
         check(lib.mi355_sumsq_f32(self.grad.data_ptr(), self.state.data_ptr(), n, s), "sumsq")
         check(lib.mi355_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                    self.flat16.data_ptr(), self.hyper.data_ptr(), self.state.data_ptr(), n, s), "adamw")
-        self.unet.refresh_operands(cast=False)
+        if not self.frozen_base:          # a frozen base keeps its operand copies; the adapters are read as fp32 masters
+            self.unet.refresh_operands(cast=False)
 
     def step(self, lr=None, grad_prescale=1.0):
         self.set_hyper(lr, grad_prescale)
@@ -174,7 +180,9 @@ class FusedAdamW:
     def _param_views(self, flat):
         views = []
         for p in self.unet.parameters():
-            o, n = self.unet._offs[id(p)], p.numel()
+            if self.frozen_base and not p.requires_grad:
+                continue
+            o, n = self.unet._offs[id(p)] - self.base, p.numel()
             if p.dim() == 4:
                 co, ci, kh, kw = p.shape
                 views.append(flat[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2))
@@ -223,7 +231,8 @@ class DenoiserTrainer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.reducer = None
         if self.world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1":
-            self.reducer = GradBucketReducer(unet.enable_direct_grads(), unet._n_big, unet._grad_packs, group=group,
+            n_big = 0 if self.opt.frozen_base else unet._n_big       # adapters only: one small tail bucket
+            self.reducer = GradBucketReducer(unet.enable_direct_grads(), n_big, unet._grad_packs, group=group,
                                              bucket_mb=bucket_mb)
         dev = self.opt.flat.device
         if alphas_cumprod is None:
@@ -256,6 +265,7 @@ class DenoiserTrainer:
                 self.wgrad_queue.join()
         finally:
             self._ops.set_wgrad_queue(None)
+        self.unet.finish_grads()
         if self.reducer is not None:
             self.reducer.finish()
         return loss.detach()

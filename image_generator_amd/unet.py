@@ -200,10 +200,7 @@ class Attention(nn.Module):
             src = context if self.is_cross else x
             a = AttentionFn.apply(self.to_q(x).contiguous(), self.to_k(src).contiguous(), self.to_v(src).contiguous(),
                                   self.heads)
-        out = self.to_out[0]
-        if isinstance(out, HipLinear):
-            return out(a, residual=residual)
-        return out(a) + residual
+        return self.to_out[0](a, residual=residual)
 
 
 class GEGLU(nn.Module):
@@ -377,6 +374,7 @@ class UNet2DConditionModel(nn.Module):
         self._flat = None
         self._flat16 = None
         self._flat_grad = None
+        self._frozen_base = False
         self._layout = None
         self._sig = None
 
@@ -404,15 +402,23 @@ class UNet2DConditionModel(nn.Module):
                              if isinstance(m, ResnetBlock) and isinstance(m.time_emb_proj, HipLinear)]
         tw = {id(l.weight) for l in self._temb_layers}
         tb = {id(l.bias) for l in self._temb_layers}
+        from .lora import LoRALinear
+        self._adapters = [m for m in self.modules() if isinstance(m, LoRALinear)]
+        ad = {id(p) for m in self._adapters for p in (m.lora_A.weight, m.lora_B.weight)}
         big = [l.weight for l in self._temb_layers] + [p for p in params if id(p) in wid and id(p) not in tw]
-        small = [l.bias for l in self._temb_layers] + [p for p in params if id(p) not in wid and id(p) not in tb]
+        small = [l.bias for l in self._temb_layers] + [p for p in params if id(p) not in wid and id(p) not in tb and id(p) not in ad]
+        adapters = [p for p in params if id(p) in ad]          # last, contiguous: the trainable range of a LoRA fine-tune
         offs, off = {}, 0
-        for p in big + small:
+        for p in big + small + adapters:
             offs[id(p)] = off
             off += _ceil8(p.numel())
         self._n_big = sum(_ceil8(p.numel()) for p in big)
+        self._adapter_range = (off - sum(_ceil8(p.numel()) for p in adapters), off)
+        # operand copies depend on the GEMM weights (and on the biases of channel-padded convs) only
+        self._sig_params = [p for p in params if id(p) in wid] + [m.bias for m in self.modules()
+                                                                  if isinstance(m, HipConv2d) and m.padded]
         flat = torch.zeros(off, dtype=F32, device=dev)
-        for p in big + small:
+        for p in big + small + adapters:
             o, n = offs[id(p)], p.numel()
             if p.dim() == 4:
                 co, ci, kh, kw = p.shape
@@ -494,7 +500,7 @@ class UNet2DConditionModel(nn.Module):
             self._build_flat()
 
     def _signature(self):
-        return tuple(p._version for p in self._plist)
+        return tuple(p._version for p in self._sig_params)
 
     def refresh_operands(self, cast=True):
         """Re-derive every bf16 operand from the fp32 masters (call after the parameters changed)."""
@@ -524,13 +530,50 @@ class UNet2DConditionModel(nn.Module):
         self._ensure_flat()
         return self._flat, self._flat16
 
+    def trainable_range(self):
+        """[start, end) of the flat storage the optimizer owns: everything, or - with a frozen base and LoRA adapters
+        as the only trainable parameters - the adapters' contiguous tail."""
+        self._ensure_flat()
+        req = [p.requires_grad for p in self._plist]
+        if all(req):
+            return 0, self._flat.numel()
+        ad = {id(p) for m in self._adapters for p in (m.lora_A.weight, m.lora_B.weight)}
+        if ad and all(p.requires_grad == (id(p) in ad) for p in self._plist):
+            return self._adapter_range
+        raise NotImplementedError("fused training supports all parameters trainable, or exactly the LoRA adapters")
+
     def enable_direct_grads(self):
         """Weight gradients of all GEMM layers are written straight into one flat fp32 buffer
-        (`param.grad` are views of it); small parameters accumulate into its tail through autograd."""
+        (`param.grad` are views of it); small parameters accumulate into its tail through autograd.
+        With a frozen base the buffer covers the adapters only and their kernels accumulate into it."""
         self._ensure_flat()
-        if self._flat_grad is None:
-            self._flat_grad = torch.zeros_like(self._flat)
+        t0, t1 = self.trainable_range()
+        self._frozen_base = t0 != 0
+        if self._flat_grad is None or self._flat_grad.numel() != t1 - t0:
+            self._flat_grad = torch.zeros(t1 - t0, dtype=F32, device=self._flat.device)
+            self._zero_table = None
+            # adapter gradients are accumulated with atomics by hundreds of workgroups per layer: 16 copies keep the
+            # fan-in per address low, `finish_grads()` sums them into the flat buffer once per step
+            self._grad_parts = torch.zeros((16, t1 - t0), dtype=F32, device=self._flat.device) if self._frozen_base else None
         g = self._flat_grad
+        if self._frozen_base:
+            for p in self._plist:
+                p.grad = None
+            for kind, m, pk, o in self._packs:
+                pk.grad_out = pk.bias_grad_out = None
+            for m in self.modules():
+                if isinstance(m, (HipGroupNorm, HipLayerNorm)):
+                    m.grad_dst = None
+            parts = self._grad_parts
+            for m in self._adapters:
+                views = []
+                for p in (m.lora_A.weight, m.lora_B.weight):
+                    o = self._offs[id(p)] - t0
+                    p.grad = g[o:o + p.numel()].view(p.shape)
+                    views.append(parts[0, o:o + p.numel()].view(p.shape))
+                m.grad_dst = (views[0], views[1], parts.shape[0], parts.shape[1])
+            self._grad_packs = []
+            return g
         for p in self.parameters():
             o, n = self._offs[id(p)], p.numel()
             if p.dim() == 4:
@@ -538,6 +581,8 @@ class UNet2DConditionModel(nn.Module):
                 p.grad = g[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
             else:
                 p.grad = g[o:o + n].view(p.shape)
+        for m in self._adapters:
+            m.grad_dst = None
         fused_members = set()
         for kind, m, pk, o in self._packs:
             if kind == "fused":
@@ -567,12 +612,21 @@ class UNet2DConditionModel(nn.Module):
                 m.grad_dst = g[ow:ow + 2 * c].view(2, c) if ob == ow + c else None
         return g
 
+    def finish_grads(self):
+        """After backward: fold the sliced adapter-gradient copies into the flat buffer (frozen-base mode only)."""
+        if self._frozen_base and self._flat_grad is not None:
+            p = self._grad_parts
+            check(lib.mi355_sum_rows_f32(p.data_ptr(), self._flat_grad.data_ptr(), p.shape[0], p.shape[1], _stream()), "sum_rows")
+
     def zero_small_grads(self, weights_too=True):
         """Direct-gradient mode: clear what the backward pass ACCUMULATES into.  Bias sums, small parameters and
         the weights that go through autograd's `+=` (channel-padded convs) always; the big weight region only when
         `weights_too` - a weight-gradient queue with `zero_split_outputs` clears its pixel-split destinations
         itself, and unsplit jobs overwrite theirs, so ~95 % of the 3.4 GB buffer need not be touched."""
         if self._flat_grad is None:
+            return
+        if self._frozen_base:
+            check(lib.mi355_zero_f32(self._grad_parts.data_ptr(), self._grad_parts.numel(), _stream()), "zero")
             return
         if weights_too:
             check(lib.mi355_zero_f32(self._flat_grad.data_ptr(), self._flat_grad.numel(), _stream()), "zero")

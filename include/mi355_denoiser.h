@@ -45,13 +45,15 @@ int mi355_prof_collect(double* ms, double* work, long long* count);
 /* ---- contractions (image_generator.py:124: Linear / Conv2d layers of the denoiser) -------------
  * out[M][N] = alpha * A[M][K] . Bw[N][K]^T + bias[n] + rowbias[m / rowbias_div][n]
  *             + lora_alpha * (lora_t[m][:] . lora_b[n][:]) + residual[m][n]
- * A, Bw, residual bf16; bias, rowbias, lora_t ([M][r]), lora_b ([N][r]) fp32; out bf16 or fp32.
+ * A, Bw, residual bf16; bias, rowbias, lora_t ([M][lora_ldt], first r columns), lora_b fp32; out bf16 or fp32.
+ * lora_b is [N][r], or [r][N] when lora_rmajor (the data-gradient GEMM passes lora_A as stored).  lora_seg > 0:
+ * the N outputs are row-stacked adapters of lora_seg outputs each and adapter s uses lora_t[m][s*r .. s*r + r).
  * Optional pointers may be NULL.  N, K and all leading dimensions must be multiples of 8. */
 size_t mi355_gemm_workspace_bytes(int M, int N);
 int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
                     int out_fp32, const float* bias, const float* rowbias, int rowbias_div, int ld_rowbias,
-                    const void* residual, int ldr, float alpha, const float* lora_t, const float* lora_b, int lora_r,
-                    float lora_alpha, void* workspace, size_t workspace_bytes, void* stream);
+                    const void* residual, int ldr, float alpha, const float* lora_t, int lora_ldt, const float* lora_b, int lora_r,
+                    int lora_seg, int lora_rmajor, float lora_alpha, void* workspace, size_t workspace_bytes, void* stream);
 
 /* 3x3 stride-2 convolution with one pixel of zero padding on the bottom and right only (the AutoencoderKL
  * down-sampler reached through image_generator.py:107-108 `self.vae.encode`): x [B][H][W][C] -> out [B][H/2][W/2][Cout]. */
@@ -172,8 +174,12 @@ int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16,
 /* ---- LoRA (lora.py:23-24): rank-r side products around the fused GEMM epilogue --------------------*/
 int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* stream);       /* t = x A^T */
 int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* stream);
-int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int out_transposed,
-                     void* stream);
+/* out[c][r] = scale * sum_m y[m][c] t[m][r].  flags bit 0: out is [R][C]; bit 1: add to `out` instead of overwriting.
+ * slices > 1 (needs bit 1): the sum is spread over `slices` copies of out, slice_stride floats apart, to keep the
+ * atomic fan-in per address low; the caller adds the copies up (mi355_sum_rows_f32). */
+int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int flags,
+                     int slices, long long slice_stride, void* stream);
+int mi355_sum_rows_f32(const float* partial, float* out, int R, long long N, void* stream);   /* out[n] = sum_r partial[r][n] */
 
 #ifdef __cplusplus
 }

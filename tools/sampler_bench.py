@@ -33,38 +33,38 @@ def sampler(args):
 
 def lora(args):
     from image_generator_amd.generator import inject_lora
-    from image_generator_amd.ops import mse_loss
+    from image_generator_amd.trainer import DenoiserTrainer
     from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
     torch.manual_seed(0)
     with torch.device("cuda:0"):
         unet = UNet2DConditionModel(DenoiserConfig.sd_v1())
     adapters = inject_lora(unet, r=4, alpha=1.0)
-    unet.to("cuda:0")
-    params = [p for p in unet.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-2, foreach=True)
+    with torch.no_grad():
+        for ad in adapters:                      # B = 0 at init would leave half of the arithmetic multiplying zeros
+            ad.lora_B.weight.normal_(0, 0.02)
+    n_train = sum(p.numel() for p in unet.parameters() if p.requires_grad)
+    tr = DenoiserTrainer(unet, lr=1e-4, weight_decay=1e-2, max_grad_norm=1.0)
     B = args.batch
     lat, noise = torch.randn(B, 4, 32, 32, device="cuda:0"), torch.randn(B, 4, 32, 32, device="cuda:0")
     ts = torch.randint(0, 1000, (B,), device="cuda:0")
     ctx = torch.randn(B, 77, 768, device="cuda:0").to(torch.bfloat16)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = mse_loss(unet(lat, ts, encoder_hidden_states=ctx).sample, noise)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
-        return loss
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(json.dumps({"mode": "lora", "adapters": len(adapters), "trainable_params": sum(p.numel() for p in params),
-                      "batch": B, "images_per_s": B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                      "loss": float(loss)}))
+    for graph in (False, True):
+        if graph:
+            tr.capture(lat, noise, ts, ctx)
+        for _ in range(3):
+            tr.train_step(lat, noise, ts, ctx)
+        torch.cuda.synchronize()
+        probe = tr.opt.flat[:4096].clone()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = tr.train_step(lat, noise, ts, ctx)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"mode": "lora", "hip_graph": graph, "adapters": len(adapters), "trainable_params": n_train,
+                          "batch": B, "images_per_s": B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                          "mfma_frac": 2 * 180.3e9 * B * args.steps / dt / 2.5e15,
+                          "loss": float(loss), "grad_norm": tr.opt.grad_norm(),
+                          "weights_moved": not torch.equal(probe, tr.opt.flat[:4096])}))
 
 
 if __name__ == "__main__":
