@@ -451,8 +451,10 @@ __global__ void clip_temp_clamp_kernel(const float* __restrict__ log_temp, float
 
 // ---- LoRA skinny products
 // t[m][r] = sum_k x[m][k] * A[r][k]     (x bf16 [M][K], A fp32 [R][K], R <= 16), one wave per row
+// t16 (optional): bf16 [M][8] copy scale16 * t, columns >= R zero - the operand the MFMA weight-gradient kernel reads.
 __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, const float* __restrict__ A,
-                                                        float* __restrict__ t, int M, int K, int R) {
+                                                        float* __restrict__ t, int M, int K, int R,
+                                                        bf16_t* __restrict__ t16, float scale16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -471,19 +473,23 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
             }
         }
     }
+    bf16x8 h = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (r < R) {
             const float s = wave_sum(acc[r]);
             if (lane == 0) t[(size_t)row * R + r] = s;
+            if (r < 8) h[r] = (bf16_t)(s * scale16);
         }
     }
+    if (t16 && lane == 0) *(bf16x8*)(t16 + (size_t)row * 8) = h;
 }
 // dt[m][r] = alpha * sum_n dy[m][n] * Bm[n][r]   (dy bf16 [M][N], Bm fp32 [N][R]); one wave per row.
 // R4: rank 4, each column's four factors are one 16-byte load.
 template <bool R4>
 __global__ __launch_bounds__(256) void lora_dt_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ Bm,
-                                                      float* __restrict__ dt, int M, int N, int R, float alpha) {
+                                                      float* __restrict__ dt, int M, int N, int R, float alpha,
+                                                      bf16_t* __restrict__ dt16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -512,27 +518,28 @@ __global__ __launch_bounds__(256) void lora_dt_kernel(const bf16_t* __restrict__
             }
         }
     }
+    bf16x8 h = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
         if (r < R) {
-            const float s = wave_sum(acc[r]);
-            if (lane == 0) dt[(size_t)row * R + r] = s * alpha;
+            const float s = wave_sum(acc[r]) * alpha;
+            if (lane == 0) dt[(size_t)row * R + r] = s;
+            if (r < 8) h[r] = (bf16_t)s;
         }
     }
+    if (dt16 && lane == 0) *(bf16x8*)(dt16 + (size_t)row * 8) = h;
 }
 // out[c][r] += scale * sum_m y[m][c] * t[m][r]   (y bf16 [M][C], t fp32 [M][R]); out fp32 [C][R] (or [R][C] when
 // `transposed`), zeroed beforehand.  Serves dB (y = dy, t = x A^T, scale = alpha) and dA (y = x, t = dt, scale = 1).
 // A workgroup is NC = C/8 column chunks x RL row lanes; it walks `rows_per_block` rows, combines the row lanes
-// through LDS and adds its [C][R] partial to the result with atomics.  Hundreds of workgroups adding to the same
-// few thousand addresses serialise in L2 (measured ~100 us per call), so the caller may offer `slices` copies of
-// the result `slice_stride` floats apart: workgroup b adds to copy b % slices and the caller sums the copies.
+// through LDS and adds its [C][R] partial to the result with atomics.  fp32 atomics retire at ~15 G/s on this
+// part, so the grid is kept small (C*R atomics per workgroup); a training step uses the MFMA weight-gradient
+// queue on bf16 copies of t instead and keeps this kernel for stand-alone adapters.
 template <bool R4>
 __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restrict__ y, const float* __restrict__ t,
                                                          float* __restrict__ out, int M, int C, int R, float scale,
-                                                         int rows_per_block, int NC, int RL, int transposed,
-                                                         int slices, long long slice_stride) {
+                                                         int rows_per_block, int NC, int RL, int transposed) {
     constexpr int RA = R4 ? 4 : 16;
-    out += (size_t)(blockIdx.x % slices) * slice_stride;
     extern __shared__ float red[];          // [RL-1][NC][8*RA] partials of row lanes 1..RL-1
     const int tid = threadIdx.x;
     const int c8 = tid % NC, rl = tid / NC;
@@ -605,6 +612,17 @@ __global__ __launch_bounds__(256) void lora_outer_kernel(const bf16_t* __restric
                     float* dst = transposed ? out + (size_t)r * C + c0 + e : out + (size_t)(c0 + e) * R + r;
                     atomicAdd(dst, acc[e][r] * scale);
                 }
+    }
+}
+
+__global__ __launch_bounds__(256) void copy2d_batched_kernel(const long long* __restrict__ table) {
+    const long long* e = table + 6 * blockIdx.y;
+    const float* src = (const float*)e[0];
+    float* dst = (float*)e[1];
+    const long long rows = e[2], cols = e[3], sld = e[4], dld = e[5];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * cols; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols, c = i - r * cols;
+        dst[r * dld + c] = src[r * sld + c];
     }
 }
 
@@ -772,23 +790,23 @@ int mi355_contrastive_loss_fused(const float* text, const float* image, const fl
     return mi355_check_launch("contrastive_loss_fused");
 }
 
-int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* stream) {
-    if (!x || !A || !t || (K & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_down: bad arguments (K%%8, 1<=R<=16)");
-    hipLaunchKernelGGL(lora_down_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)x, A, t, M, K, R);
+int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* t16, float scale16, void* stream) {
+    if (!x || !A || !t || (K & 7) || R < 1 || R > 16 || (t16 && R > 8))
+        return mi355_fail(MI355_ERR_ARG, "lora_down: bad arguments (K%%8, 1<=R<=16, R<=8 with a bf16 copy)");
+    hipLaunchKernelGGL(lora_down_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)x, A, t, M, K, R, (bf16_t*)t16, scale16);
     return mi355_check_launch("lora_down");
 }
-int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* stream) {
-    if (!dy || !Bm || !dt || (N & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_dt: bad arguments");
-    if (R == 4) hipLaunchKernelGGL(lora_dt_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha);
-    else hipLaunchKernelGGL(lora_dt_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha);
+int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* dt16, void* stream) {
+    if (!dy || !Bm || !dt || (N & 7) || R < 1 || R > 16 || (dt16 && R > 8)) return mi355_fail(MI355_ERR_ARG, "lora_dt: bad arguments");
+    if (R == 4) hipLaunchKernelGGL(lora_dt_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha, (bf16_t*)dt16);
+    else hipLaunchKernelGGL(lora_dt_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha, (bf16_t*)dt16);
     return mi355_check_launch("lora_dt");
 }
 // flags: bit 0 = result laid out [R][C] instead of [C][R]; bit 1 = accumulate into `out` (the caller zeroed it, or
 // wants the sum with its previous contents) instead of overwriting it
 int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int flags,
-                     int slices, long long slice_stride, void* stream) {
-    if (!y || !t || !out || (C & 7) || R < 1 || R > 16 || M < 1 || slices < 1 || (slices > 1 && !(flags & 2)))
-        return mi355_fail(MI355_ERR_ARG, "lora_outer: bad arguments");
+                     void* stream) {
+    if (!y || !t || !out || (C & 7) || R < 1 || R > 16 || M < 1) return mi355_fail(MI355_ERR_ARG, "lora_outer: bad arguments");
     if (!(flags & 2)) mi355_zero_async(out, (size_t)C * R * sizeof(float), ST);
     const int nc_all = C / 8;
     const int NC = nc_all < 256 ? nc_all : 256;               // column chunks per workgroup
@@ -797,23 +815,23 @@ int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, in
     const int rl_cap = 1 + (48 * 1024) / (NC * 8 * RA * (int)sizeof(float));
     if (RL > rl_cap) RL = rl_cap;
     const int gy = (nc_all + NC - 1) / NC;
-    int rows = (M + 255) / 256;                                // ~256 workgroups, at least 8 rows per row lane
-    if (rows < 8 * RL) rows = 8 * RL;
+    int rows = (M + 63) / 64;                                  // ~64 workgroups, at least 16 rows per row lane
+    if (rows < 16 * RL) rows = 16 * RL;
     const int gx = (M + rows - 1) / rows;
     const size_t smem = (size_t)(RL - 1) * NC * 8 * RA * sizeof(float);
     if (R == 4)
         hipLaunchKernelGGL(lora_outer_kernel<true>, dim3(gx, gy), dim3(256), smem, ST, (const bf16_t*)y, t, out, M, C, R, scale,
-                           rows, NC, RL, flags & 1, slices, slice_stride);
+                           rows, NC, RL, flags & 1);
     else
         hipLaunchKernelGGL(lora_outer_kernel<false>, dim3(gx, gy), dim3(256), smem, ST, (const bf16_t*)y, t, out, M, C, R, scale,
-                           rows, NC, RL, flags & 1, slices, slice_stride);
+                           rows, NC, RL, flags & 1);
     return mi355_check_launch("lora_outer");
 }
-// out[n] = sum_r partial[r][n]   (fp32, N a multiple of 4)
-int mi355_sum_rows_f32(const float* partial, float* out, int R, long long N, void* stream) {
-    if (!partial || !out || R < 1 || N < 4 || (N & 3) || N > 0x7fffffffLL) return mi355_fail(MI355_ERR_ARG, "sum_rows: bad arguments");
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64), 1), dim3(256), 0, ST, partial, out, R, (int)N, (float*)nullptr, 0);
-    return mi355_check_launch("sum_rows");
+// Batched strided 2-D copy of fp32 blocks: table holds n records {src, dst, rows, cols, src_ld, dst_ld} (int64).
+int mi355_copy2d_f32_batched(const long long* table, int n, void* stream) {
+    if (!table || n < 1) return mi355_fail(MI355_ERR_ARG, "copy2d_batched: bad arguments");
+    hipLaunchKernelGGL(copy2d_batched_kernel, dim3(16, n), dim3(256), 0, ST, table);
+    return mi355_check_launch("copy2d_batched");
 }
 
 }  // extern "C"

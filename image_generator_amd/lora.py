@@ -13,7 +13,8 @@ import torch
 import torch.nn as nn
 
 from ._lib import lib, check
-from .ops import BF16, F32, _stream, gemm
+from . import ops as _ops
+from .ops import BF16, F32, _ptr, _stream, gemm
 
 
 def _operands(original):
@@ -39,9 +40,13 @@ def _f32c(p):
 
 
 class _LoraLinearFn(torch.autograd.Function):
-    """y = x W^T + b + alpha * (x A^T) B^T (+ residual).  `gdst` = (dA, dB, slices, stride): fp32 views into the first
-    of `slices` zeroed copies (stride floats apart) of a flat gradient buffer; the adapter gradients are accumulated
-    over the copies and their owner sums them once per step.  Without it they are returned to autograd."""
+    """y = x W^T + b + alpha * (x A^T) B^T (+ residual).
+
+    `gdst` = (dA_pad [8][K], dB_pad [N][8]) fp32 scratch views: when a weight-gradient queue is installed (a training
+    step of DenoiserTrainer) the adapter gradients dB = alpha dy^T (x A^T) and dA = dt^T x are two more jobs of the
+    grouped MFMA weight-gradient launch, computed from bf16 [M][8] copies of x A^T and dt and written zero-padded to
+    8 ranks; their owner compacts them into the flat gradient buffer once per step.  Without a queue the fp32
+    reduction kernels run and the gradients are returned to autograd."""
 
     @staticmethod
     def forward(ctx, x, a, b, bias, alpha, w16, w16_t, residual, gdst):
@@ -54,43 +59,45 @@ class _LoraLinearFn(torch.autograd.Function):
         M, r, N = x2.shape[0], a.shape[0], b.shape[0]
         af, bf = _f32c(a), _f32c(b)
         t = torch.empty((M, r), dtype=F32, device=x.device)
-        check(lib.mi355_lora_down(x2.data_ptr(), af.data_ptr(), t.data_ptr(), M, K, r, _stream()), "lora_down")
+        queued = gdst is not None and r <= 8 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        t16 = torch.empty((M, 8), dtype=BF16, device=x.device) if queued else None
+        check(lib.mi355_lora_down(x2.data_ptr(), af.data_ptr(), t.data_ptr(), M, K, r, _ptr(t16), alpha, _stream()), "lora_down")
         biasf = None if bias is None else _f32c(bias)
         res2 = None if residual is None else residual.reshape(-1, N)
         y = gemm(x2, w16, bias=biasf, residual=res2, lora_t=t, lora_b=bf, lora_alpha=alpha)
-        ctx.save_for_backward(x2, t, af, bf)
+        ctx.save_for_backward(x2, t, af, bf, t16)
         ctx.alpha, ctx.w16_t, ctx.xshape, ctx.xdtype, ctx.gdst = alpha, w16_t, x.shape, x.dtype, gdst
         y = y.view(*x.shape[:-1], N)
         return y if x.dtype == BF16 else y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, t, af, bf = ctx.saved_tensors
+        x2, t, af, bf, t16 = ctx.saved_tensors
         M, K = x2.shape
         N, r = bf.shape
         dy2 = dy.reshape(-1, N)
         if dy2.dtype != BF16 or not dy2.is_contiguous():
             dy2 = dy2.to(BF16).contiguous()
         s = _stream()
+        queue = _ops._WGRAD_QUEUE if (ctx.gdst is not None and t16 is not None) else None
         dt = torch.empty((M, r), dtype=F32, device=dy.device)
-        check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, ctx.alpha, s), "lora_dt")
+        dt16 = torch.empty((M, 8), dtype=BF16, device=dy.device) if queue is not None else None
+        check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, ctx.alpha, _ptr(dt16), s), "lora_dt")
         da = db = None
         want_a, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        if ctx.gdst is not None:
-            ga, gb, slices, stride = ctx.gdst
-            if want_b:
-                check(lib.mi355_lora_outer(dy2.data_ptr(), t.data_ptr(), gb.data_ptr(), M, N, r, ctx.alpha, 2, slices, stride, s),
-                      "lora_outer")
-            if want_a:
-                check(lib.mi355_lora_outer(x2.data_ptr(), dt.data_ptr(), ga.data_ptr(), M, K, r, 1.0, 3, slices, stride, s),
-                      "lora_outer")
+        if queue is not None:
+            ga, gb = ctx.gdst
+            if want_b:          # dB_pad[n][0:8] = sum_m dy[m][n] * (alpha t)[m][0:8]
+                queue.push(dy2, t16, gb, None, M, 1, 1, 8, N, 1, 1, False, 1, 1)
+            if want_a:          # dA_pad[0:8][k] = sum_m dt[m][0:8] * x[m][k]
+                queue.push(dt16, x2, ga, None, M, 1, 1, K, 8, 1, 1, False, 1, 1)
         else:
             if want_b:
                 db = torch.empty((N, r), dtype=F32, device=dy.device)
-                check(lib.mi355_lora_outer(dy2.data_ptr(), t.data_ptr(), db.data_ptr(), M, N, r, ctx.alpha, 0, 1, 0, s), "lora_outer")
+                check(lib.mi355_lora_outer(dy2.data_ptr(), t.data_ptr(), db.data_ptr(), M, N, r, ctx.alpha, 0, s), "lora_outer")
             if want_a:
                 da = torch.empty((r, K), dtype=F32, device=dy.device)
-                check(lib.mi355_lora_outer(x2.data_ptr(), dt.data_ptr(), da.data_ptr(), M, K, r, 1.0, 1, 1, 0, s), "lora_outer")
+                check(lib.mi355_lora_outer(x2.data_ptr(), dt.data_ptr(), da.data_ptr(), M, K, r, 1.0, 1, s), "lora_outer")
         dx = None
         if ctx.needs_input_grad[0]:
             # dx = dy W + dt A : the rank-r term rides in the epilogue of the data-gradient GEMM (A as stored, [r][K])
@@ -115,7 +122,7 @@ class LoRALinear(nn.Module):
         nn.init.zeros_(self.lora_B.weight)
         for p in self.original.parameters():
             p.requires_grad = False
-        self.grad_dst = None        # (dA, dB, slices, stride) into a sliced flat gradient buffer in direct-gradient mode
+        self.grad_dst = None        # (dA_pad [8][K], dB_pad [N][8]) scratch views in direct-gradient mode
 
     def forward(self, x, residual=None):
         """`residual` (optional, beyond the reference signature) is added in the same GEMM epilogue."""

@@ -552,9 +552,7 @@ class UNet2DConditionModel(nn.Module):
         if self._flat_grad is None or self._flat_grad.numel() != t1 - t0:
             self._flat_grad = torch.zeros(t1 - t0, dtype=F32, device=self._flat.device)
             self._zero_table = None
-            # adapter gradients are accumulated with atomics by hundreds of workgroups per layer: 16 copies keep the
-            # fan-in per address low, `finish_grads()` sums them into the flat buffer once per step
-            self._grad_parts = torch.zeros((16, t1 - t0), dtype=F32, device=self._flat.device) if self._frozen_base else None
+            self._grad_pad = None
         g = self._flat_grad
         if self._frozen_base:
             for p in self._plist:
@@ -564,14 +562,24 @@ class UNet2DConditionModel(nn.Module):
             for m in self.modules():
                 if isinstance(m, (HipGroupNorm, HipLayerNorm)):
                     m.grad_dst = None
-            parts = self._grad_parts
+            # The adapter gradients come out of the grouped weight-gradient launch zero-padded to 8 ranks
+            # (dA_pad [8][K], dB_pad [N][8]); `finish_grads()` compacts them into the flat buffer with one launch.
+            if any(m.r > 8 for m in self._adapters):
+                raise NotImplementedError("fused LoRA training supports ranks up to 8")
+            n_pad = sum(8 * (m.lora_A.weight.shape[1] + m.lora_B.weight.shape[0]) for m in self._adapters)
+            pad = self._grad_pad = torch.zeros(n_pad, dtype=F32, device=g.device)
+            table, q = [], 0
             for m in self._adapters:
-                views = []
-                for p in (m.lora_A.weight, m.lora_B.weight):
-                    o = self._offs[id(p)] - t0
-                    p.grad = g[o:o + p.numel()].view(p.shape)
-                    views.append(parts[0, o:o + p.numel()].view(p.shape))
-                m.grad_dst = (views[0], views[1], parts.shape[0], parts.shape[1])
+                A, Bm = m.lora_A.weight, m.lora_B.weight
+                r, K, N = A.shape[0], A.shape[1], Bm.shape[0]
+                oa, ob = self._offs[id(A)] - t0, self._offs[id(Bm)] - t0
+                A.grad, Bm.grad = g[oa:oa + r * K].view(r, K), g[ob:ob + N * r].view(N, r)
+                ga, gb = pad[q:q + 8 * K].view(8, K), pad[q + 8 * K:q + 8 * (K + N)].view(N, 8)
+                q += 8 * (K + N)
+                m.grad_dst = (ga, gb)
+                table.append([ga.data_ptr(), A.grad.data_ptr(), r, K, K, K])
+                table.append([gb.data_ptr(), Bm.grad.data_ptr(), N, r, 8, r])
+            self._compact_table = torch.tensor(table, dtype=torch.int64, device=g.device)
             self._grad_packs = []
             return g
         for p in self.parameters():
@@ -613,10 +621,11 @@ class UNet2DConditionModel(nn.Module):
         return g
 
     def finish_grads(self):
-        """After backward: fold the sliced adapter-gradient copies into the flat buffer (frozen-base mode only)."""
+        """After backward (and after the weight-gradient queue was joined): compact the rank-padded adapter gradients
+        into the flat buffer (frozen-base mode only)."""
         if self._frozen_base and self._flat_grad is not None:
-            p = self._grad_parts
-            check(lib.mi355_sum_rows_f32(p.data_ptr(), self._flat_grad.data_ptr(), p.shape[0], p.shape[1], _stream()), "sum_rows")
+            t = self._compact_table
+            check(lib.mi355_copy2d_f32_batched(t.data_ptr(), t.shape[0], _stream()), "copy2d_batched")
 
     def zero_small_grads(self, weights_too=True):
         """Direct-gradient mode: clear what the backward pass ACCUMULATES into.  Bias sums, small parameters and
@@ -625,8 +634,8 @@ class UNet2DConditionModel(nn.Module):
         itself, and unsplit jobs overwrite theirs, so ~95 % of the 3.4 GB buffer need not be touched."""
         if self._flat_grad is None:
             return
-        if self._frozen_base:
-            check(lib.mi355_zero_f32(self._grad_parts.data_ptr(), self._grad_parts.numel(), _stream()), "zero")
+        if self._frozen_base:       # an adapter that does not run backward this step must end up with a zero gradient
+            check(lib.mi355_zero_f32(self._grad_pad.data_ptr(), self._grad_pad.numel(), _stream()), "zero")
             return
         if weights_too:
             check(lib.mi355_zero_f32(self._flat_grad.data_ptr(), self._flat_grad.numel(), _stream()), "zero")

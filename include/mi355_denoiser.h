@@ -172,14 +172,16 @@ int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16,
                      long long n, void* stream);
 
 /* ---- LoRA (lora.py:23-24): rank-r side products around the fused GEMM epilogue --------------------*/
-int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* stream);       /* t = x A^T */
-int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* stream);
+/* t = x A^T (fp32 [M][R]).  t16 (optional, R <= 8): bf16 [M][8] copy scale16 * t, zero beyond column R. */
+int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* t16, float scale16, void* stream);
+/* dt = alpha * dy B (fp32 [M][R]); dt16 (optional, R <= 8): its bf16 [M][8] copy. */
+int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* dt16, void* stream);
 /* out[c][r] = scale * sum_m y[m][c] t[m][r].  flags bit 0: out is [R][C]; bit 1: add to `out` instead of overwriting.
- * slices > 1 (needs bit 1): the sum is spread over `slices` copies of out, slice_stride floats apart, to keep the
- * atomic fan-in per address low; the caller adds the copies up (mi355_sum_rows_f32). */
+ * (A training step computes the same sums on the MFMA weight-gradient queue from the bf16 copies above.) */
 int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int flags,
-                     int slices, long long slice_stride, void* stream);
-int mi355_sum_rows_f32(const float* partial, float* out, int R, long long N, void* stream);   /* out[n] = sum_r partial[r][n] */
+                     void* stream);
+/* n records {src, dst, rows, cols, src_ld, dst_ld} (int64, device memory): dst[r][c] = src[r][c], fp32. */
+int mi355_copy2d_f32_batched(const long long* table, int n, void* stream);
 
 #ifdef __cplusplus
 }
