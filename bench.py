@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--small", action="store_true", help="plumbing-size model (NOT the headline config)")
     ap.add_argument("--no-graph", action="store_true", help="run the eager step even on one GPU")
+    ap.add_argument("--lora", action="store_true",
+                    help="LoRA fine-tune step instead of the headline full fine-tune: frozen base, rank-4 adapters on "
+                         "attn{1,2}.to_{q,k,v,out} (no cpu_baseline leg)")
     return ap.parse_args()
 
 
@@ -84,6 +87,13 @@ def main():
     cfg = DenoiserConfig.small() if args.small else DenoiserConfig.sd_v1()
     with torch.device(dev):
         unet = UNet2DConditionModel(cfg)
+    if args.lora:
+        from image_generator_amd.generator import inject_lora
+        adapters = inject_lora(unet, r=4, alpha=1.0)
+        torch.manual_seed(4321)
+        with torch.no_grad():               # the zero-initialised up-projections would make half the arithmetic trivial
+            for ad in adapters:
+                ad.lora_B.weight.normal_(0, 0.02)
     trainer = DenoiserTrainer(unet, lr=1e-4, weight_decay=1e-2, max_grad_norm=1.0)
     B, L = args.batch, args.latent
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -154,19 +164,22 @@ def main():
                                      "achieved": (p["work_per_step"] / (p["ms_per_step"] * 1e-3) / 1e12) if p["ms_per_step"] > 0 else 0.0,
                                      "unit": "TFLOP/s" if f in ("gemm_conv", "wgrad", "attention") else "TB/s",
                                      "launches": p["launches_per_step"]} for f, p in prof.items()}}
-        step_flops = 3 * FWD_GFLOP_PER_SAMPLE_256 * 1e9 * B * (L / 32.0) ** 2
+        step_flops = (2 if args.lora else 3) * FWD_GFLOP_PER_SAMPLE_256 * 1e9 * B * (L / 32.0) ** 2
         out = {"metric": "train images/sec (whole node) at 256^2 bf16", "value": value, "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic (random latents/text states in HBM, random-init weights)",
-               "config": {"workload": "denoiser train step 256x256 (latent 32x32), SD-v1 UNet 859.5M params, "
-                                      "text cross-attention T=77" if not args.small else "small plumbing model",
+               "config": {"workload": ("small plumbing model" if args.small else
+                                       "LoRA fine-tune step 256x256 (latent 32x32), frozen SD-v1 UNet 859.5M params, 128 rank-4 "
+                                       "adapters (797k trainable), text cross-attention T=77" if args.lora else
+                                       "denoiser train step 256x256 (latent 32x32), SD-v1 UNet 859.5M params, "
+                                       "text cross-attention T=77"),
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                           "optimizer": "fused AdamW + global-norm clip", "final_loss": final_loss, "final_grad_norm": gnorm,
                           "hip_graph": bool(graphed)},
                "step_mfma_frac": step_flops / (ms * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12) if not args.small else None,
                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.lora:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
     if dist.is_initialized():

@@ -473,61 +473,78 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
             }
         }
     }
-    bf16x8 h = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 h[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (r < R) {
             const float s = wave_sum(acc[r]);
             if (lane == 0) t[(size_t)row * R + r] = s;
-            if (r < 8) h[r] = (bf16_t)(s * scale16);
+            h[r >> 3][r & 7] = (bf16_t)(s * scale16);
         }
     }
-    if (t16 && lane == 0) *(bf16x8*)(t16 + (size_t)row * 8) = h;
+    if (t16 && lane == 0) {
+        if (R <= 8) *(bf16x8*)(t16 + (size_t)row * 8) = h[0];
+        else { *(bf16x8*)(t16 + (size_t)row * 16) = h[0]; *(bf16x8*)(t16 + (size_t)row * 16 + 8) = h[1]; }
+    }
 }
-// dt[m][r] = alpha * sum_n dy[m][n] * Bm[n][r]   (dy bf16 [M][N], Bm fp32 [N][R]); one wave per row.
-// R4: rank 4, each column's four factors are one 16-byte load.
+// dt[m][s*R + r] = alpha * sum_{n in segment s} dy[m][n] * Bm[n][r]   (dy bf16 [M][N], Bm fp32 [N][R], N = S * seg:
+// S row-stacked adapters of one fused projection; S = 1 is a single adapter).  One wave per row.
+// R4: rank 4 (S <= 4), each column's four factors are one 16-byte load.  dt16 (optional): bf16 copy, 8 columns when
+// S*R <= 8, else 16, zero padded.
 template <bool R4>
 __global__ __launch_bounds__(256) void lora_dt_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ Bm,
-                                                      float* __restrict__ dt, int M, int N, int R, float alpha,
+                                                      float* __restrict__ dt, int M, int N, int R, int S, float alpha,
                                                       bf16_t* __restrict__ dt16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    constexpr int RA = R4 ? 4 : 16;
-    float acc[RA];
+    float acc[16];
 #pragma unroll
-    for (int r = 0; r < RA; ++r) acc[r] = 0.f;
-    for (int n = lane * 8; n < N; n += 512) {
-        const bf16x8 dv = *(const bf16x8*)(dy + (size_t)row * N + n);
-        if (R4) {
-            const f32x4* bp = (const f32x4*)(Bm + (size_t)n * 4);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (R4) {
+        const int seg = N / S;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const f32x4 bv = bp[e];
-                const float d = (float)dv[e];
+        for (int sg = 0; sg < 4; ++sg) {
+            if (sg < S) {
+                for (int n = sg * seg + lane * 8; n < (sg + 1) * seg; n += 512) {
+                    const bf16x8 dv = *(const bf16x8*)(dy + (size_t)row * N + n);
+                    const f32x4* bp = (const f32x4*)(Bm + (size_t)n * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] += d * bv[r];
+                    for (int e = 0; e < 8; ++e) {
+                        const f32x4 bv = bp[e];
+                        const float d = (float)dv[e];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[sg * 4 + r] += d * bv[r];
+                    }
+                }
             }
-        } else {
+        }
+    } else {
+        for (int n = lane * 8; n < N; n += 512) {
+            const bf16x8 dv = *(const bf16x8*)(dy + (size_t)row * N + n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float d = (float)dv[e];
 #pragma unroll
-                for (int r = 0; r < RA; ++r)
+                for (int r = 0; r < 16; ++r)
                     if (r < R) acc[r] += d * Bm[(size_t)(n + e) * R + r];
             }
         }
     }
-    bf16x8 h = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int RT = R * S;
+    bf16x8 h[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
 #pragma unroll
-    for (int r = 0; r < RA; ++r) {
-        if (r < R) {
+    for (int r = 0; r < 16; ++r) {
+        if (r < RT) {
             const float s = wave_sum(acc[r]) * alpha;
-            if (lane == 0) dt[(size_t)row * R + r] = s;
-            if (r < 8) h[r] = (bf16_t)s;
+            if (lane == 0) dt[(size_t)row * RT + r] = s;
+            h[r >> 3][r & 7] = (bf16_t)s;
         }
     }
-    if (dt16 && lane == 0) *(bf16x8*)(dt16 + (size_t)row * 8) = h;
+    if (dt16 && lane == 0) {
+        if (RT <= 8) *(bf16x8*)(dt16 + (size_t)row * 8) = h[0];
+        else { *(bf16x8*)(dt16 + (size_t)row * 16) = h[0]; *(bf16x8*)(dt16 + (size_t)row * 16 + 8) = h[1]; }
+    }
 }
 // out[c][r] += scale * sum_m y[m][c] * t[m][r]   (y bf16 [M][C], t fp32 [M][R]); out fp32 [C][R] (or [R][C] when
 // `transposed`), zeroed beforehand.  Serves dB (y = dy, t = x A^T, scale = alpha) and dA (y = x, t = dt, scale = 1).
@@ -791,15 +808,15 @@ int mi355_contrastive_loss_fused(const float* text, const float* image, const fl
 }
 
 int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* t16, float scale16, void* stream) {
-    if (!x || !A || !t || (K & 7) || R < 1 || R > 16 || (t16 && R > 8))
-        return mi355_fail(MI355_ERR_ARG, "lora_down: bad arguments (K%%8, 1<=R<=16, R<=8 with a bf16 copy)");
+    if (!x || !A || !t || (K & 7) || R < 1 || R > 16) return mi355_fail(MI355_ERR_ARG, "lora_down: bad arguments (K%%8, 1<=R<=16)");
     hipLaunchKernelGGL(lora_down_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)x, A, t, M, K, R, (bf16_t*)t16, scale16);
     return mi355_check_launch("lora_down");
 }
-int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* dt16, void* stream) {
-    if (!dy || !Bm || !dt || (N & 7) || R < 1 || R > 16 || (dt16 && R > 8)) return mi355_fail(MI355_ERR_ARG, "lora_dt: bad arguments");
-    if (R == 4) hipLaunchKernelGGL(lora_dt_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha, (bf16_t*)dt16);
-    else hipLaunchKernelGGL(lora_dt_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, alpha, (bf16_t*)dt16);
+int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, int S, float alpha, void* dt16, void* stream) {
+    if (!dy || !Bm || !dt || (N & 7) || R < 1 || S < 1 || R * S > 16 || N % S || ((N / S) & 7) || (S > 1 && R != 4))
+        return mi355_fail(MI355_ERR_ARG, "lora_dt: bad arguments (R*S <= 16; stacked adapters need rank 4)");
+    if (R == 4) hipLaunchKernelGGL(lora_dt_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, S, alpha, (bf16_t*)dt16);
+    else hipLaunchKernelGGL(lora_dt_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16_t*)dy, Bm, dt, M, N, R, S, alpha, (bf16_t*)dt16);
     return mi355_check_launch("lora_dt");
 }
 // flags: bit 0 = result laid out [R][C] instead of [C][R]; bit 1 = accumulate into `out` (the caller zeroed it, or

@@ -82,7 +82,7 @@ class _LoraLinearFn(torch.autograd.Function):
         queue = _ops._WGRAD_QUEUE if (ctx.gdst is not None and t16 is not None) else None
         dt = torch.empty((M, r), dtype=F32, device=dy.device)
         dt16 = torch.empty((M, 8), dtype=BF16, device=dy.device) if queue is not None else None
-        check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, ctx.alpha, _ptr(dt16), s), "lora_dt")
+        check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, 1, ctx.alpha, _ptr(dt16), s), "lora_dt")
         da = db = None
         want_a, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         if queue is not None:
@@ -107,6 +107,71 @@ class _LoraLinearFn(torch.autograd.Function):
                 dx = dx.to(ctx.xdtype)
         dres = dy if ctx.needs_input_grad[7] else None
         return dx, da, db, None, None, None, None, dres, None
+
+
+class LoraFusedFn(torch.autograd.Function):
+    """Row-stacked projections that read the same input (q/k/v of self-attention, k/v of cross-attention), each with
+    its own rank-4 adapter, as ONE GEMM: y[:, s] = x W_s^T + alpha * (x A_s^T) B_s^T.
+
+    `lf` carries zero-copy stacked views of the adapters' factors (`A_all` [S*r][K], `B_all` [S*C][r]; the owning
+    model lays the parameters out back to back) and, in direct-gradient mode, the rank-padded scratch views
+    `grad_dst` = (dA_pad [W][K], dB_pad [S*C][W]), W = 8 or 16.  `params` = the 2*S factor parameters
+    (A_0, B_0, A_1, B_1, ...) for autograd's bookkeeping."""
+
+    @staticmethod
+    def forward(ctx, x, pack, lf, *params):
+        if not x.is_cuda:
+            raise RuntimeError("LoRA: HIP device tensors required (no CPU path)")
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.dtype != BF16 or not x2.is_contiguous():
+            x2 = x2.to(BF16).contiguous()
+        M, N, RT = x2.shape[0], pack.n, lf.S * lf.r
+        want = any(ctx.needs_input_grad[3:])
+        W = 8 if RT <= 8 else 16
+        t = torch.empty((M, RT), dtype=F32, device=x.device)
+        t16 = torch.empty((M, W), dtype=BF16, device=x.device) if want else None
+        check(lib.mi355_lora_down(x2.data_ptr(), lf.A_all.data_ptr(), t.data_ptr(), M, K, RT, _ptr(t16), lf.alpha, _stream()),
+              "lora_down")
+        y = gemm(x2, pack.w16.view(N, K), lora_t=t, lora_b=lf.B_all, lora_alpha=lf.alpha, lora_seg=N // lf.S)
+        ctx.save_for_backward(x2, t16)
+        ctx.pack, ctx.lf, ctx.xshape, ctx.W = pack, lf, x.shape, W
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, t16 = ctx.saved_tensors
+        pack, lf, W = ctx.pack, ctx.lf, ctx.W
+        M, K = x2.shape
+        N, S, r = pack.n, lf.S, lf.r
+        C = N // S
+        dy2 = dy.reshape(-1, N)
+        if dy2.dtype != BF16 or not dy2.is_contiguous():
+            dy2 = dy2.to(BF16).contiguous()
+        want = t16 is not None
+        dt = torch.empty((M, S * r), dtype=F32, device=dy.device)
+        dt16 = torch.empty((M, W), dtype=BF16, device=dy.device) if want else None
+        check(lib.mi355_lora_dt(dy2.data_ptr(), lf.B_all.data_ptr(), dt.data_ptr(), M, N, r, S, lf.alpha, _ptr(dt16), _stream()),
+              "lora_dt")
+        grads = [None] * (2 * S)
+        if want:
+            queue = _ops._WGRAD_QUEUE if lf.grad_dst is not None else None
+            if queue is not None:
+                ga, gb = lf.grad_dst
+                queue.push(dy2, t16, gb, None, M, 1, 1, W, N, 1, 1, False, 1, 1)       # dB_pad = dy^T (alpha t)
+                queue.push(dt16, x2, ga, None, M, 1, 1, K, W, 1, 1, False, 1, 1)       # dA_pad = dt^T x
+            else:
+                gb = _ops.wgrad(dy2, t16, W, N).view(N, W)
+                ga = _ops.wgrad(dt16, x2, K, W).view(W, K)
+                for i in range(S):
+                    if ctx.needs_input_grad[3 + 2 * i]:
+                        grads[2 * i] = ga[i * r:(i + 1) * r]
+                    if ctx.needs_input_grad[4 + 2 * i]:
+                        grads[2 * i + 1] = gb[i * C:(i + 1) * C, i * r:(i + 1) * r]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dy2, pack.w16_t.view(K, N), lora_t=dt, lora_b=lf.A_all, lora_alpha=1.0, lora_rmajor=True).view(ctx.xshape)
+        return (dx, None, None, *grads)
 
 
 class LoRALinear(nn.Module):

@@ -182,6 +182,7 @@ class Attention(nn.Module):
             self.fused_pack.n, self.fused_pack.k = 2 * query_dim, context_dim
         else:
             self.fused_pack.n, self.fused_pack.k = 3 * query_dim, query_dim
+        self.lora_fused = None      # stacked views of the projections' adapters (set by the owning UNet)
 
     def _plain(self):
         return all(isinstance(m, HipLinear) for m in (self.to_q, self.to_k, self.to_v))
@@ -196,6 +197,16 @@ class Attention(nn.Module):
                 qkv = LinearFn.apply(x, self.fused_pack, None, None, False, self.to_q.weight, self.to_k.weight,
                                      self.to_v.weight)
                 a = AttentionFn.apply(qkv, None, None, self.heads)
+        elif self.lora_fused is not None and self.fused_pack.w16 is not None:
+            # adapters around projections that share their input: one GEMM for the row-stacked base weights, the
+            # adapters' rank-4 terms in its epilogue
+            from .lora import LoraFusedFn
+            lf = self.lora_fused
+            if self.is_cross:
+                kv = LoraFusedFn.apply(context, self.fused_pack, lf, *lf.params)
+                a = AttentionFn.apply(self.to_q(x).contiguous(), kv, None, self.heads)
+            else:
+                a = AttentionFn.apply(LoraFusedFn.apply(x, self.fused_pack, lf, *lf.params), None, None, self.heads)
         else:   # adapters (LoRALinear) wrapped around the projections
             src = context if self.is_cross else x
             a = AttentionFn.apply(self.to_q(x).contiguous(), self.to_k(src).contiguous(), self.to_v(src).contiguous(),
@@ -405,9 +416,25 @@ class UNet2DConditionModel(nn.Module):
         from .lora import LoRALinear
         self._adapters = [m for m in self.modules() if isinstance(m, LoRALinear)]
         ad = {id(p) for m in self._adapters for p in (m.lora_A.weight, m.lora_B.weight)}
+        # adapters around projections that share an input are laid out [A_0 .. A_S-1 | B_0 .. B_S-1] so that their
+        # stacked factors are views of the flat storage
+        fused_groups, ordered, seen = [], [], set()
+        for m in self.modules():
+            if isinstance(m, Attention):
+                m.lora_fused = None
+                ws = [m.to_k, m.to_v] if m.is_cross else [m.to_q, m.to_k, m.to_v]
+                if (all(isinstance(w, LoRALinear) and isinstance(w.original, HipLinear) and w.r == 4 for w in ws)
+                        and len({w.alpha for w in ws}) == 1):
+                    fused_groups.append((m, ws))
+                    for w in ws:
+                        ordered.append(w.lora_A.weight)
+                    for w in ws:
+                        ordered.append(w.lora_B.weight)
+                    seen.update(id(p) for w in ws for p in (w.lora_A.weight, w.lora_B.weight))
         big = [l.weight for l in self._temb_layers] + [p for p in params if id(p) in wid and id(p) not in tw]
         small = [l.bias for l in self._temb_layers] + [p for p in params if id(p) not in wid and id(p) not in tb and id(p) not in ad]
-        adapters = [p for p in params if id(p) in ad]          # last, contiguous: the trainable range of a LoRA fine-tune
+        # last, contiguous: the trainable range of a LoRA fine-tune
+        adapters = ordered + [p for p in params if id(p) in ad and id(p) not in seen]
         offs, off = {}, 0
         for p in big + small + adapters:
             offs[id(p)] = off
@@ -453,6 +480,7 @@ class UNet2DConditionModel(nn.Module):
             if isinstance(m, Attention):
                 pk = m.fused_pack
                 ws = [m.to_k, m.to_v] if m.is_cross else [m.to_q, m.to_k, m.to_v]
+                ws = [w.original if isinstance(w, LoRALinear) else w for w in ws]
                 if not all(isinstance(w, HipLinear) for w in ws):
                     pk.w16 = None
                     continue
@@ -465,6 +493,16 @@ class UNet2DConditionModel(nn.Module):
                 pk.w16 = self._flat16[o0:o0 + pk.n * pk.k].view(pk.n, pk.k)
                 pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
                 self._packs.append(("fused", m, pk, o0))
+        from types import SimpleNamespace
+        for m, ws in fused_groups:
+            if m.fused_pack.w16 is None:
+                continue
+            S, r, K, C = len(ws), ws[0].r, ws[0].lora_A.weight.shape[1], ws[0].lora_B.weight.shape[0]
+            oa, ob = offs[id(ws[0].lora_A.weight)], offs[id(ws[0].lora_B.weight)]
+            m.lora_fused = SimpleNamespace(
+                S=S, r=r, alpha=float(ws[0].alpha), mods=ws, grad_dst=None,
+                A_all=flat[oa:oa + S * r * K].view(S * r, K), B_all=flat[ob:ob + S * C * r].view(S * C, r),
+                params=[p for w in ws for p in (w.lora_A.weight, w.lora_B.weight)])
         self._temb_pack = None
         tl = self._temb_layers
         if len(tl) > 1 and all(l.weight.numel() % 8 == 0 and l.bias.numel() % 8 == 0 for l in tl):
@@ -566,7 +604,14 @@ class UNet2DConditionModel(nn.Module):
             # (dA_pad [8][K], dB_pad [N][8]); `finish_grads()` compacts them into the flat buffer with one launch.
             if any(m.r > 8 for m in self._adapters):
                 raise NotImplementedError("fused LoRA training supports ranks up to 8")
-            n_pad = sum(8 * (m.lora_A.weight.shape[1] + m.lora_B.weight.shape[0]) for m in self._adapters)
+            groups = [m.lora_fused for m in self.modules() if isinstance(m, Attention) and m.lora_fused is not None]
+            in_group = {id(w) for lf in groups for w in lf.mods}
+            singles = [m for m in self._adapters if id(m) not in in_group]
+
+            def width(rt):
+                return 8 if rt <= 8 else 16
+            n_pad = sum(8 * (m.lora_A.weight.shape[1] + m.lora_B.weight.shape[0]) for m in singles)
+            n_pad += sum(width(lf.S * lf.r) * (lf.A_all.shape[1] + lf.B_all.shape[0]) for lf in groups)
             pad = self._grad_pad = torch.zeros(n_pad, dtype=F32, device=g.device)
             table, q = [], 0
             for m in self._adapters:
@@ -574,11 +619,25 @@ class UNet2DConditionModel(nn.Module):
                 r, K, N = A.shape[0], A.shape[1], Bm.shape[0]
                 oa, ob = self._offs[id(A)] - t0, self._offs[id(Bm)] - t0
                 A.grad, Bm.grad = g[oa:oa + r * K].view(r, K), g[ob:ob + N * r].view(N, r)
+                m.grad_dst = None
+            for m in singles:
+                A, Bm = m.lora_A.weight, m.lora_B.weight
+                r, K, N = A.shape[0], A.shape[1], Bm.shape[0]
                 ga, gb = pad[q:q + 8 * K].view(8, K), pad[q + 8 * K:q + 8 * (K + N)].view(N, 8)
                 q += 8 * (K + N)
                 m.grad_dst = (ga, gb)
                 table.append([ga.data_ptr(), A.grad.data_ptr(), r, K, K, K])
                 table.append([gb.data_ptr(), Bm.grad.data_ptr(), N, r, 8, r])
+            for lf in groups:
+                S, r, K, N = lf.S, lf.r, lf.A_all.shape[1], lf.B_all.shape[0]
+                W, C = width(S * r), N // S
+                ga, gb = pad[q:q + W * K].view(W, K), pad[q + W * K:q + W * (K + N)].view(N, W)
+                q += W * (K + N)
+                lf.grad_dst = (ga, gb)
+                # the group's A gradients are adjacent in the flat buffer (same order as the factors themselves)
+                table.append([ga.data_ptr(), lf.mods[0].lora_A.weight.grad.data_ptr(), S * r, K, K, K])
+                for i, w in enumerate(lf.mods):
+                    table.append([gb.data_ptr() + 4 * (i * C * W + i * r), w.lora_B.weight.grad.data_ptr(), C, r, W, r])
             self._compact_table = torch.tensor(table, dtype=torch.int64, device=g.device)
             self._grad_packs = []
             return g
@@ -591,6 +650,9 @@ class UNet2DConditionModel(nn.Module):
                 p.grad = g[o:o + n].view(p.shape)
         for m in self._adapters:
             m.grad_dst = None
+        for m in self.modules():
+            if isinstance(m, Attention) and m.lora_fused is not None:
+                m.lora_fused.grad_dst = None
         fused_members = set()
         for kind, m, pk, o in self._packs:
             if kind == "fused":

@@ -172,10 +172,12 @@ int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16,
                      long long n, void* stream);
 
 /* ---- LoRA (lora.py:23-24): rank-r side products around the fused GEMM epilogue --------------------*/
-/* t = x A^T (fp32 [M][R]).  t16 (optional, R <= 8): bf16 [M][8] copy scale16 * t, zero beyond column R. */
+/* t = x A^T (fp32 [M][R]; A may be several adapters' factors stacked, R <= 16).  t16 (optional): bf16 copy
+ * scale16 * t, [M][8] when R <= 8 else [M][16], zero padded. */
 int mi355_lora_down(const void* x, const float* A, float* t, int M, int K, int R, void* t16, float scale16, void* stream);
-/* dt = alpha * dy B (fp32 [M][R]); dt16 (optional, R <= 8): its bf16 [M][8] copy. */
-int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, float alpha, void* dt16, void* stream);
+/* dt[m][s*R + r] = alpha * sum_{n in segment s} dy[m][n] Bm[n][r]: S adapters row-stacked in Bm [N][R] (S = 1: one
+ * adapter; S > 1 needs R = 4, R*S <= 16).  dt16 (optional): bf16 copy, [M][8] when R*S <= 8 else [M][16]. */
+int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int R, int S, float alpha, void* dt16, void* stream);
 /* out[c][r] = scale * sum_m y[m][c] t[m][r].  flags bit 0: out is [R][C]; bit 1: add to `out` instead of overwriting.
  * (A training step computes the same sums on the MFMA weight-gradient queue from the bf16 copies above.) */
 int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int flags,
