@@ -420,7 +420,7 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
                         void* stream) {
-    if (!x || !dy || !stats || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch)
+    if (!x || !dy || !stats || !gamma || !beta || !dx || !scratch || (!dgamma != !dbeta))
         return mi355_fail(MI355_ERR_ARG, "groupnorm_bwd: null pointer");
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
@@ -433,8 +433,9 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
                        (const bf16_t*)dy, stats, gamma, beta, gpart, cpart, HW, C, G, rows, silu);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st,
                        (const bf16_t*)x, (const bf16_t*)dy, stats, gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu);
-    // dbeta = column sums of the first plane, dgamma of the second
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B * strips, 2 * C, dgamma, C);
+    // dbeta = column sums of the first plane, dgamma of the second (skipped for frozen affine parameters)
+    if (dgamma)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B * strips, 2 * C, dgamma, C);
     return mi355_check_launch("groupnorm_bwd");
 }
 
@@ -460,7 +461,7 @@ long long mi355_layernorm_bwd_scratch_floats(int M, int C) { return (long long)l
 // scratch: mi355_layernorm_bwd_scratch_floats().
 int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx,
                         float* dgamma_dbeta, float* scratch, int M, int C, void* stream) {
-    if (!x || !dy || !stats || !gamma || !dx || !dgamma_dbeta || !scratch)
+    if (!x || !dy || !stats || !gamma || !dx || !scratch)
         return mi355_fail(MI355_ERR_ARG, "layernorm_bwd: null pointer");
     if (C % 8 || C > 8 * 64 * LN_MAXCH) return mi355_fail(MI355_ERR_UNSUPPORTED, "layernorm: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
@@ -484,7 +485,8 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
     else if (C <= 1536) LN_BWD(3);
     else LN_BWD(4);
 #undef LN_BWD
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, scratch, dgamma_dbeta, grid, 2 * C);
+    if (dgamma_dbeta)       // null: frozen affine parameters, only dx is wanted
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, scratch, dgamma_dbeta, grid, 2 * C);
     return mi355_check_launch("layernorm_bwd");
 }
 

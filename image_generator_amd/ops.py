@@ -495,12 +495,13 @@ class GroupNormFn(torch.autograd.Function):
         G = ctx.groups
         dx = torch.empty_like(x)
         direct = ctx.gdst is not None
-        dg, db = ctx.gdst if direct else (torch.empty_like(gamma), torch.empty_like(beta))
+        frozen = not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])      # affine parameters without gradient
+        dg, db = ctx.gdst if direct else ((None, None) if frozen else (torch.empty_like(gamma), torch.empty_like(beta)))
         scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, G)), dtype=F32, device=x.device)
         check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                      dx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), B, H * W, C, G,
+                                      dx.data_ptr(), _ptr(dg), _ptr(db), scratch.data_ptr(), B, H * W, C, G,
                                       int(ctx.silu), _stream()), "groupnorm_bwd")
-        if direct:
+        if direct or frozen:
             return dx, None, None, None, None, None, None
         return dx, dg, db, None, None, None, None
 
@@ -527,11 +528,12 @@ class LayerNormFn(torch.autograd.Function):
         M = x.numel() // C
         dx = torch.empty_like(x)
         direct = ctx.gdst is not None
-        dgb = ctx.gdst if direct else torch.empty((2, C), dtype=F32, device=x.device)
+        frozen = not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dgb = ctx.gdst if direct else (None if frozen else torch.empty((2, C), dtype=F32, device=x.device))
         scratch = torch.empty(int(lib.mi355_layernorm_bwd_scratch_floats(M, C)), dtype=F32, device=x.device)
         check(lib.mi355_layernorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                                      dgb.data_ptr(), scratch.data_ptr(), M, C, _stream()), "layernorm_bwd")
-        if direct:
+                                      _ptr(dgb), scratch.data_ptr(), M, C, _stream()), "layernorm_bwd")
+        if direct or frozen:
             return dx, None, None, None, None
         return dx, dgb[0], dgb[1], None, None
 
