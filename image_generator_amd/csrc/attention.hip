@@ -39,15 +39,19 @@ __host__ __device__ constexpr int tr_ld(int no) { return (no * 64) % 128 == 64 ?
 // filled), split in two so the global loads of the NEXT tile are in flight while the current tile is
 // being multiplied: tile_load() fills NCH registers per thread (chunk idx = threadIdx.x + 256*i), tile_store()
 // writes them to LDS after the barrier that retires the current tile.
-template <int NCH>
+// ONES: column D of every row (the first padding column) holds 1.0 instead of 0 - a product with this tile then
+// carries the row sums of the other operand in that column for free.
+template <int NCH, bool ONES = false>
 __device__ __forceinline__ void tile_load(bf16x8 (&reg)[NCH], const bf16_t* __restrict__ src, int ld, int rows_valid, int D,
                                           int nrows, int ncols8) {
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16x8 one8 = {(bf16_t)1.0f, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int idx = threadIdx.x + 256 * i;
         const int r = idx / ncols8, c = idx - r * ncols8;
-        reg[i] = (idx < nrows * ncols8 && r < rows_valid && c * 8 < D) ? *(const bf16x8*)(src + (size_t)r * ld + c * 8) : zero8;
+        reg[i] = (idx < nrows * ncols8 && r < rows_valid && c * 8 < D) ? *(const bf16x8*)(src + (size_t)r * ld + c * 8)
+                                                                        : ((ONES && c * 8 == D) ? one8 : zero8);
     }
 }
 template <int NCH>
@@ -63,7 +67,9 @@ __device__ __forceinline__ void tile_store(const bf16x8 (&reg)[NCH], char* dst, 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int ND, int NO>
+// ONES (needs D < 32 * NO): the softmax denominators are accumulated by the P V product itself, through a column of
+// ones in the V tile's padding - 32 fewer additions per lane and key tile in a loop that is VALU-bound at small D.
+template <int ND, int NO, bool ONES>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int DP = 16 * ND;
     constexpr int KLD = DP * 2 + 16;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int NCK = (64 * (DP / 8) + 255) / 256, NCV = (64 * NO * 4 + 255) / 256;
     bf16x8 kreg[NCK], vreg[NCV];
     tile_load(kreg, Kb, p.ldk, Nk, p.D, 64, DP / 8);
-    tile_load(vreg, Vb, p.ldv, Nk, p.D, 64, NO * 4);
+    tile_load<NCV, ONES>(vreg, Vb, p.ldv, Nk, p.D, 64, NO * 4);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         __syncthreads();
         if (kt + 1 < nkt) {                       // next tile's loads fly under this tile's MFMAs and softmax
             tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, Nk - k0 - 64, p.D, 64, DP / 8);
-            tile_load(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, Nk - k0 - 64, p.D, 64, NO * 4);
+            tile_load<NCV, ONES>(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, Nk - k0 - 64, p.D, 64, NO * 4);
         }
 
         f32x16 s[2];
@@ -148,10 +154,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const float e = EXP2(fmaf(s[kb][r], p.scale_log2, -m_new));
                 s[kb][r] = e;
-                sum += e;
+                if (!ONES) sum += e;
             }
-        sum += __shfl_xor(sum, 32, 64);
-        l = l * alpha + sum;
+        if (!ONES) {
+            sum += __shfl_xor(sum, 32, 64);
+            l = l * alpha + sum;
+        }
         // the running maximum settles after a few tiles: rescale only when some query of the wave moved it
         if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {
 #pragma unroll
@@ -183,6 +191,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 }
     }
 
+    if (ONES) {
+        // the ones column is row D % 32 of the last 32-row block of O^T: register (D % 32) / 2 of the lanes with hh = 0
+        const int c = p.D & 31;
+        const float lsum = c == 8 ? o[NO - 1][4] : c == 16 ? o[NO - 1][8] : o[NO - 1][12];
+        l = __shfl(lsum, l31, 64);
+    }
     if (q_ok) {
         const float inv = 1.f / l;
         bf16_t* Ob = p.out + ((size_t)b * p.Nq + qrow) * p.ldo + h * p.D;
@@ -448,7 +462,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
 
 template <int ND, int NO>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((attn_fwd_kernel<ND, NO>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    // a spare padding column exists: row sums ride the P V product (measured: +4 % at D = 40, N = 4096; a loss at
+    // D = 80, where the extra column costs a third 32-wide block nothing but the additions it saves are fewer per MFMA)
+    if (NO <= 2 && a.D < 32 * NO)
+        hipLaunchKernelGGL((attn_fwd_kernel<ND, NO, true>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<ND, NO, false>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
     return mi355_check_launch("attn_fwd");
 }
 template <int ND, int NO>
