@@ -184,7 +184,8 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
 __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                     const float* __restrict__ stats, const float* __restrict__ gpart,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    bf16_t* __restrict__ dx, int HW, int C, int G, int rows_per_block, int silu) {
+                                    bf16_t* __restrict__ dx, int HW, int C, int G, int rows_per_block, int silu,
+                                    const bf16_t* __restrict__ dres) {
     extern __shared__ float gs[];            // [G][2] = {sum_c gamma*sum dz, sum_c gamma*sum dz*xhat}
     const int nc = C >> 3;
     const int b = blockIdx.y;
@@ -215,6 +216,11 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
             float dz = (float)dv[e];
             if (silu) dz *= silu_grad_f(xh * ga[e] + be[e]);
             ov[e] = (bf16_t)(rs[e] * (ga[e] * dz - m1[e] - xh * m2[e]));
+        }
+        if (dres) {         // gradient of the branch that bypasses the normalisation (residual / shortcut input)
+            const bf16x8 rv = *(const bf16x8*)(dres + base + (size_t)r * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)((float)ov[e] + (float)rv[e]);
         }
         *(bf16x8*)(dx + base + (size_t)r * C) = ov;
     };
@@ -289,7 +295,7 @@ template <int NCH>
 __global__ __launch_bounds__(NCH <= 2 ? 1024 : 512) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       bf16_t* __restrict__ dx, float* __restrict__ partial,
-                                                      int M, int C) {
+                                                      int M, int C, const bf16_t* __restrict__ dres) {
     extern __shared__ float lred[];      // [waves][2][C] per-wave sums (dgamma, dbeta), then [C] gamma
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
@@ -344,6 +350,11 @@ __global__ __launch_bounds__(NCH <= 2 ? 1024 : 512) void ln_bwd_kernel(const bf1
                     const float xh = ((float)xv[k][e] - mean) * rstd;
                     const float dg = (float)dv[k][e] * (e < 4 ? g0[e] : g1[e - 4]);
                     o[e] = (bf16_t)(rstd * (dg - s1 - xh * s2));
+                }
+                if (dres) {     // gradient of the residual branch that bypasses the normalisation
+                    const bf16x8 rv = *(const bf16x8*)(dres + (size_t)row * C + c8 * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)o[e] + (float)rv[e]);
                 }
                 *(bf16x8*)(dx + (size_t)row * C + c8 * 8) = o;
             }
@@ -419,7 +430,7 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
 // scratch: mi355_groupnorm_scratch_floats().
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
-                        void* stream) {
+                        const void* dres, void* stream) {
     if (!x || !dy || !stats || !gamma || !beta || !dx || !scratch || (!dgamma != !dbeta))
         return mi355_fail(MI355_ERR_ARG, "groupnorm_bwd: null pointer");
     int threads, rpar, rows, strips;
@@ -432,7 +443,8 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
     hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x,
                        (const bf16_t*)dy, stats, gamma, beta, gpart, cpart, HW, C, G, rows, silu);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st,
-                       (const bf16_t*)x, (const bf16_t*)dy, stats, gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu);
+                       (const bf16_t*)x, (const bf16_t*)dy, stats, gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu,
+                       (const bf16_t*)dres);
     // dbeta = column sums of the first plane, dgamma of the second (skipped for frozen affine parameters)
     if (dgamma)
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B * strips, 2 * C, dgamma, C);
@@ -460,7 +472,7 @@ long long mi355_layernorm_bwd_scratch_floats(int M, int C) { return (long long)l
 // dgamma_dbeta: [2][C] floats (dgamma row, then dbeta row), overwritten.
 // scratch: mi355_layernorm_bwd_scratch_floats().
 int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx,
-                        float* dgamma_dbeta, float* scratch, int M, int C, void* stream) {
+                        float* dgamma_dbeta, float* scratch, int M, int C, const void* dres, void* stream) {
     if (!x || !dy || !stats || !gamma || !dx || !scratch)
         return mi355_fail(MI355_ERR_ARG, "layernorm_bwd: null pointer");
     if (C % 8 || C > 8 * 64 * LN_MAXCH) return mi355_fail(MI355_ERR_UNSUPPORTED, "layernorm: C=%d unsupported", C);
@@ -478,7 +490,7 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
             attr_set = true;                                                                                   \
         }                                                                                                      \
         hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(threads), sh, st, (const bf16_t*)x,            \
-                           (const bf16_t*)dy, stats, gamma, (bf16_t*)dx, scratch, M, C);                       \
+                           (const bf16_t*)dy, stats, gamma, (bf16_t*)dx, scratch, M, C, (const bf16_t*)dres); \
     } while (0)
     if (C <= 512) LN_BWD(1);
     else if (C <= 1024) LN_BWD(2);

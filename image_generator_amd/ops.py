@@ -475,8 +475,10 @@ class ConvFn(torch.autograd.Function):
 
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu, gdst=None):
-        """gdst: optional (dgamma, dbeta) fp32 views the parameter gradients are written into directly."""
+    def forward(ctx, x, gamma, beta, groups, eps, silu, gdst=None, passthrough=False):
+        """gdst: optional (dgamma, dbeta) fp32 views the parameter gradients are written into directly.
+        passthrough: also return x itself, for the branch that reads x beside the norm (residual / shortcut);
+        backward then adds that branch's gradient inside the normalisation kernel instead of a separate add."""
         B, H, W, C = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((B, groups, 2), dtype=F32, device=x.device)
@@ -485,12 +487,16 @@ class GroupNormFn(torch.autograd.Function):
                                       scratch.data_ptr(), B, H * W, C, groups, eps, int(silu), _stream()), "groupnorm_fwd")
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.groups, ctx.silu, ctx.gdst = groups, silu, gdst
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x, stats, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
+        if dpass is not None:
+            dpass = (dpass if dpass.dtype == BF16 else dpass.to(BF16)).contiguous()
         B, H, W, C = x.shape
         G = ctx.groups
         dx = torch.empty_like(x)
@@ -500,16 +506,17 @@ class GroupNormFn(torch.autograd.Function):
         scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, G)), dtype=F32, device=x.device)
         check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                       dx.data_ptr(), _ptr(dg), _ptr(db), scratch.data_ptr(), B, H * W, C, G,
-                                      int(ctx.silu), _stream()), "groupnorm_bwd")
+                                      int(ctx.silu), _ptr(dpass), _stream()), "groupnorm_bwd")
         if direct or frozen:
-            return dx, None, None, None, None, None, None
-        return dx, dg, db, None, None, None, None
+            return dx, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, gdst=None):
-        """gdst: optional fp32 [2][C] view (dgamma row, dbeta row) written directly."""
+    def forward(ctx, x, gamma, beta, eps, gdst=None, passthrough=False):
+        """gdst: optional fp32 [2][C] view (dgamma row, dbeta row) written directly.
+        passthrough: also return x for the residual branch; its gradient is added inside the backward kernel."""
         C = x.shape[-1]
         M = x.numel() // C
         y = torch.empty_like(x)
@@ -518,12 +525,16 @@ class LayerNormFn(torch.autograd.Function):
                                       M, C, eps, _stream()), "layernorm_fwd")
         ctx.save_for_backward(x, stats, gamma)
         ctx.gdst = gdst
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x, stats, gamma = ctx.saved_tensors
         dy = dy.contiguous()
+        if dpass is not None:
+            dpass = (dpass if dpass.dtype == BF16 else dpass.to(BF16)).contiguous()
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
@@ -532,10 +543,10 @@ class LayerNormFn(torch.autograd.Function):
         dgb = ctx.gdst if direct else (None if frozen else torch.empty((2, C), dtype=F32, device=x.device))
         scratch = torch.empty(int(lib.mi355_layernorm_bwd_scratch_floats(M, C)), dtype=F32, device=x.device)
         check(lib.mi355_layernorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                                      _ptr(dgb), scratch.data_ptr(), M, C, _stream()), "layernorm_bwd")
+                                      _ptr(dgb), scratch.data_ptr(), M, C, _ptr(dpass), _stream()), "layernorm_bwd")
         if direct or frozen:
-            return dx, None, None, None, None
-        return dx, dgb[0], dgb[1], None, None
+            return dx, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None
 
 
 class AttentionFn(torch.autograd.Function):

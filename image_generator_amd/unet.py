@@ -116,8 +116,11 @@ class HipGroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(channels))
         self.grad_dst = None        # (dgamma, dbeta) views of the flat gradient buffer in direct-gradient mode
 
-    def forward(self, x, silu):
-        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst)
+    def forward(self, x, silu, passthrough=False):
+        """passthrough: returns (y, x') where x' is x for the branch that bypasses the norm (see GroupNormFn)."""
+        if passthrough and not (torch.is_grad_enabled() and x.requires_grad):
+            return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst), x
+        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst, passthrough)
 
 
 class HipLayerNorm(nn.Module):
@@ -128,8 +131,10 @@ class HipLayerNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(dim))
         self.grad_dst = None        # [2][C] view (dgamma | dbeta) of the flat gradient buffer in direct-gradient mode
 
-    def forward(self, x):
-        return LayerNormFn.apply(x, self.weight, self.bias, self.eps, self.grad_dst)
+    def forward(self, x, passthrough=False):
+        if passthrough and not (torch.is_grad_enabled() and x.requires_grad):
+            return LayerNormFn.apply(x, self.weight, self.bias, self.eps, self.grad_dst), x
+        return LayerNormFn.apply(x, self.weight, self.bias, self.eps, self.grad_dst, passthrough)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -158,7 +163,7 @@ class ResnetBlock(nn.Module):
         self._tproj = None          # this block's slice of the model-wide fused time-embedding projection
 
     def forward(self, x, temb_act):
-        h = self.norm1(x, silu=True)
+        h, x = self.norm1(x, silu=True, passthrough=True)      # x: the shortcut branch's view of the input
         rb = self._tproj if self._tproj is not None else self.time_emb_proj(temb_act, out_fp32=True)
         h = self.conv1(h, rowbias=rb)
         h = self.norm2(h, silu=True)
@@ -249,9 +254,14 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, context):
-        x = self.attn1(self.norm1(x), None, x)
-        x = self.attn2(self.norm2(x), context, x)
-        return self.ff(self.norm3(x), x)
+        # each norm hands back the residual branch's view of its input: the two gradients meet inside the
+        # normalisation's backward kernel instead of in a separate addition
+        n, x = self.norm1(x, passthrough=True)
+        x = self.attn1(n, None, x)
+        n, x = self.norm2(x, passthrough=True)
+        x = self.attn2(n, context, x)
+        n, x = self.norm3(x, passthrough=True)
+        return self.ff(n, x)
 
 
 class Transformer2D(nn.Module):
@@ -264,7 +274,8 @@ class Transformer2D(nn.Module):
 
     def forward(self, x, context):
         B, H, W, C = x.shape
-        h = self.proj_in(self.norm(x, silu=False)).view(B, H * W, C)
+        h, x = self.norm(x, silu=False, passthrough=True)
+        h = self.proj_in(h).view(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
         return self.proj_out(h.view(B, H, W, C), residual=x)

@@ -112,20 +112,21 @@ int mi355_attention_bwd(const void* q, const void* k, const void* v, const void*
 /* ---- normalisation ------------------------------------------------------------------------------
  * GroupNorm over [B][HW][C] with G groups, optional fused SiLU.  stats [B][G][2] = (mean, rstd).
  * scratch (both calls): mi355_groupnorm_scratch_floats(B, HW, C, G) floats.
- * Backward: dgamma and dbeta may both be NULL (frozen affine parameters: only dx is produced). */
+ * Backward: dgamma and dbeta may both be NULL (frozen affine parameters: only dx is produced).  dres (optional,
+ * bf16, shape of x) is added to dx in the same pass: the gradient of a branch that reads x beside the norm. */
 long long mi355_groupnorm_scratch_floats(int B, int HW, int C, int G);
 int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* scratch,
                         int B, int HW, int C, int G, float eps, int silu, void* stream);
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
-                        void* stream);
+                        const void* dres, void* stream);
 /* LayerNorm over rows of [M][C]; stats [M][2] = (mean, rstd). */
 int mi355_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C,
                         float eps, void* stream);
 long long mi355_layernorm_bwd_scratch_floats(int M, int C);
-/* dgamma_dbeta: [2][C] floats (dgamma row, then dbeta row), or NULL when only dx is wanted. */
+/* dgamma_dbeta: [2][C] floats (dgamma row, then dbeta row), or NULL when only dx is wanted; dres as above. */
 int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx,
-                        float* dgamma_dbeta, float* scratch, int M, int C, void* stream);
+                        float* dgamma_dbeta, float* scratch, int M, int C, const void* dres, void* stream);
 
 /* ---- elementwise / layout -----------------------------------------------------------------------*/
 /* out[m][:] = softmax(scale * in[m][:]) over bf16 rows (single-head attention of the auto-encoder mid block) */
