@@ -35,6 +35,25 @@ struct ProfScope {
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
+// erf to ~2e-7 absolute (Abramowitz & Stegun 7.1.26) in ~12 VALU operations plus one reciprocal and one exponential;
+// the library erff costs several times that, which made the GELU gate the dominant part of the fused GEGLU epilogue.
+__device__ __forceinline__ float fast_erff(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+    return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+// erf-form GELU (torch.nn.functional.gelu default) and its derivative
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + fast_erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+    return 0.5f * (1.f + fast_erff(x * 0.70710678118654752f)) +
+           x * 0.3989422804014327f * __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -4,10 +4,8 @@
 
 #define GRID_FOR(n, per) ({ size_t _g = ((size_t)(n) + (per) - 1) / (per); if (_g > 4096) _g = 4096; if (_g < 1) _g = 1; (int)_g; })
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_f(float x) { return gelu_erf_f(x); }
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_erf_grad_f(x); }
 
 // ---- row softmax of a bf16 [M][N] score matrix (single-head attention of the auto-encoder's mid block, whose
 // head dim 512 is beyond the flash kernel): out = softmax(scale * in) per row, one wave per row, fp32 statistics

@@ -56,7 +56,7 @@ struct GemmArgs {
 
 enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2 };
 
-__device__ __forceinline__ float gemm_gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gemm_gelu_erf(float x) { return gelu_erf_f(x); }
 
 // Shared tail of both GEMM kernels: split-K slab store, or the LDS-staged vectorised epilogue.
 // Low-rank term of 8 adjacent outputs: v[e] += lora_alpha * sum_r t[m][r] * b(n + e, r).  `lora_seg` > 0: the columns
@@ -131,13 +131,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 const int row = idx / (NC / 2), c8 = idx - row * (NC / 2);
                 const int m = m0 + h * 64 + row, f = f0 + c8 * 8;
                 if (m >= p.M || f >= F) continue;
+                const float* er = ep + row * EP_LD + c8 * 8;
+                f32x4 hv[2] = {*(const f32x4*)er, *(const f32x4*)(er + 4)};
+                f32x4 gv[2] = {*(const f32x4*)(er + BN / 2), *(const f32x4*)(er + BN / 2 + 4)};
+                if (p.alpha != 1.f) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { hv[q] *= p.alpha; gv[q] *= p.alpha; }
+                }
+                if (p.bias) {
+                    const f32x4* bh = (const f32x4*)(p.bias + f);
+                    const f32x4* bg = (const f32x4*)(p.bias + F + f);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { hv[q] += bh[q]; gv[q] += bg[q]; }
+                }
                 bf16x8 ov;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float hv = ep[row * EP_LD + c8 * 8 + e] * p.alpha, gv = ep[row * EP_LD + BN / 2 + c8 * 8 + e] * p.alpha;
-                    if (p.bias) { hv += p.bias[f + e]; gv += p.bias[F + f + e]; }
-                    ov[e] = (bf16_t)(hv * gemm_gelu_erf(gv));
-                }
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)(hv[e >> 2][e & 3] * gemm_gelu_erf(gv[e >> 2][e & 3]));
                 *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + f) = ov;
             }
             continue;
@@ -152,13 +161,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = v0[e] * p.alpha; v[4 + e] = v1[e] * p.alpha; }
             if (p.bias) {
+                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
             }
             if (p.rowbias) {
                 const float* rb = p.rowbias + (size_t)(m / p.rowbias_div) * p.ld_rowbias + n;
+                const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rb[e];
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
             }
             if (p.lora_t) lora_apply(p, m, n, v);
             if (p.residual) {
@@ -516,13 +527,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
         if (p.bias) {
+            const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
         }
         if (p.rowbias) {
             const float* rb = p.rowbias + (size_t)(m / p.rowbias_div) * p.ld_rowbias + n;
+            const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rb[e];
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
         }
         if (p.lora_t) lora_apply(p, m, n, v);
         if (p.residual) {
@@ -608,6 +621,8 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
         return mi355_fail(MI355_ERR_ARG, "gemm: leading dimensions must be multiples of 8 elements");
     if (a.residual && (a.ldr & 7)) return mi355_fail(MI355_ERR_ARG, "gemm: residual stride must be a multiple of 8");
     if (a.rowbias && a.rowbias_div <= 0) return mi355_fail(MI355_ERR_ARG, "gemm: rowbias_div must be positive");
+    if (((uintptr_t)a.bias & 15) || ((uintptr_t)a.rowbias & 15) || (a.rowbias && (a.ld_rowbias & 3)))
+        return mi355_fail(MI355_ERR_ARG, "gemm: bias / rowbias must be 16-byte aligned (rowbias stride a multiple of 4 floats)");
     int bn;
     if (a.N % 160 == 0) bn = 160;
     else if (a.N <= 64) bn = 64;
