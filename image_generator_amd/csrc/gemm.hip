@@ -49,7 +49,8 @@ struct GemmArgs {
     float lora_alpha;
     float* partial;          // split-K slabs [splitk][M][N] fp32
     int splitk, kt_per_split;
-    int geglu;               // fused GEGLU (inference): N = 2F weight rows (hidden | gate), out [M][F] = h * gelu(g)
+    int geglu;               // fused GEGLU: N = 2F weight rows (hidden | gate), out [M][F] = h * gelu(g)
+    bf16_t* preact;          // geglu only, optional: [M][2F] pre-activation (hidden | gate) kept for the backward pass
     int tiles_m, tiles_n;
     ConvGeom g;
 };
@@ -145,8 +146,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     for (int q = 0; q < 2; ++q) { hv[q] += bh[q]; gv[q] += bg[q]; }
                 }
                 bf16x8 ov;
+                if (p.preact) {     // training: the gate is applied to the bf16-rounded values the backward pass will read
+                    bf16x8 hb, gb;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)(hv[e >> 2][e & 3] * gemm_gelu_erf(gv[e >> 2][e & 3]));
+                    for (int e = 0; e < 8; ++e) { hb[e] = (bf16_t)hv[e >> 2][e & 3]; gb[e] = (bf16_t)gv[e >> 2][e & 3]; }
+                    *(bf16x8*)(p.preact + (size_t)m * p.N + f) = hb;
+                    *(bf16x8*)(p.preact + (size_t)m * p.N + F + f) = gb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)((float)hb[e] * gemm_gelu_erf((float)gb[e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)(hv[e >> 2][e & 3] * gemm_gelu_erf(gv[e >> 2][e & 3]));
+                }
                 *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + f) = ov;
             }
             continue;
@@ -707,11 +718,12 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
 }
 
 int mi355_gemm_geglu_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int F, int K, void* out, int ldo,
-                          const float* bias, void* stream) {
+                          const float* bias, void* preact, void* stream) {
     if (!A || !Bw || !out) return mi355_fail(MI355_ERR_ARG, "gemm_geglu: null pointer");
     GemmArgs a = {};
     a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = 2 * F; a.K = K; a.lda = lda; a.ldb = ldb;
     a.out = out; a.ldo = ldo; a.out_fp32 = 0; a.bias = bias; a.rowbias_div = 1; a.alpha = 1.f; a.geglu = 1;
+    a.preact = (bf16_t*)preact;
     a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
     return run_gemm(a, AMODE_DENSE, nullptr, 0, (hipStream_t)stream);
 }

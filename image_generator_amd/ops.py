@@ -76,15 +76,17 @@ def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=F
     return out
 
 
-def gemm_geglu(a, w, bias=None):
-    """out[M,F] = (a @ w[:F]^T + b[:F]) * gelu(a @ w[F:]^T + b[F:]) in one launch (no-grad path of the GEGLU block)."""
+def gemm_geglu(a, w, bias=None, keep_preact=False):
+    """out[M,F] = (a @ w[:F]^T + b[:F]) * gelu(a @ w[F:]^T + b[F:]) in one launch.
+    keep_preact: also return the bf16 [M, 2F] pre-activation (hidden | gate) for a backward pass."""
     M, K = a.shape
     F2 = w.shape[0]
     assert a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.is_contiguous() and w.shape[1] == K
     out = torch.empty((M, F2 // 2), dtype=BF16, device=a.device)
+    pre = torch.empty((M, F2), dtype=BF16, device=a.device) if keep_preact else None
     check(lib.mi355_gemm_geglu_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), K, M, F2 // 2, K, out.data_ptr(), F2 // 2,
-                                    _ptr(bias), _stream()), "gemm_geglu")
-    return out
+                                    _ptr(bias), _ptr(pre), _stream()), "gemm_geglu")
+    return (out, pre) if keep_preact else out
 
 
 def conv2d(x, w, cout, ksize, stride=1, ups=False, dil=False, out_hw=None, bias=None, rowbias=None, residual=None,
@@ -338,16 +340,21 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x2,) = ctx.saved_tensors
+        return LinearFn._backward(ctx, x2, dy, ctx.needs_input_grad)
+
+    @staticmethod
+    def _backward(ctx, x2, dy, needs):
+        """Data, weight and bias gradients of y = x W^T (+ b) (+ residual); `needs` has LinearFn.forward's layout."""
         pack = ctx.pack
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.dtype != BF16:
             dy2 = dy2.to(BF16)
         dy2 = dy2.contiguous()
         dx = db = dres = None
-        if ctx.needs_input_grad[0]:
+        if needs[0]:
             dx = gemm(dy2, pack.w16_t.view(pack.k, pack.n)).view(ctx.xshape)
-        want_db = ctx.has_bias and (ctx.needs_input_grad[2] or any(ctx.breq))
-        if ctx.has_res and ctx.needs_input_grad[3]:
+        want_db = ctx.has_bias and (needs[2] or any(ctx.breq))
+        if ctx.has_res and needs[3]:
             dres = dy2.view(dy.shape)
         dws = [None] * len(ctx.wshapes)
         if any(ctx.wreq):
@@ -383,6 +390,33 @@ class LinearFn(torch.autograd.Function):
                 r0 += shp[0]
             db = None
         return (dx, None, db, dres, None, *dws, *dbs)
+
+
+class GegluLinearFn(torch.autograd.Function):
+    """GEGLU input projection in one GEMM: y = h * gelu(g) with (h | g) = x W^T + b.  The epilogue also stores the
+    bf16 pre-activation for backward, so the [M][2F] matrix is written once and never re-read in the forward pass."""
+
+    @staticmethod
+    def forward(ctx, x, pack, bias, weight):
+        x2 = x.reshape(-1, x.shape[-1])
+        y, pre = gemm_geglu(x2, pack.w16.view(pack.n, pack.k), bias, keep_preact=True)
+        ctx.save_for_backward(x2, pre)
+        ctx.pack, ctx.xshape = pack, x.shape
+        ctx.has_bias, ctx.has_res = bias is not None, False
+        ctx.bshapes, ctx.breq = [], []
+        ctx.wshapes, ctx.wreq = [weight.shape], [weight.requires_grad]
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre = ctx.saved_tensors
+        dy = dy.contiguous()
+        F2 = pre.shape[1]
+        dpre = torch.empty_like(pre)
+        check(lib.mi355_geglu_bwd(pre.data_ptr(), dy.data_ptr(), dpre.data_ptr(), pre.shape[0], F2 // 2, _stream()), "geglu_bwd")
+        n = ctx.needs_input_grad
+        dx, _, db, _, _, dw = LinearFn._backward(ctx, x2, dpre, (n[0], False, n[2], False, False, n[3]))
+        return dx, None, db, dw
 
 
 class SplitColsFn(torch.autograd.Function):

@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from ._lib import lib, check
 from . import ops
-from .ops import (BF16, F32, AttentionFn, ConvFn, GegluFn, GroupNormFn, LayerNormFn, LinearFn, SiluF32ToBf16Fn,
+from .ops import (BF16, F32, AttentionFn, ConvFn, GegluFn, GegluLinearFn, GroupNormFn, LayerNormFn, LinearFn, SiluF32ToBf16Fn,
                   SplitColsFn, ToNCHWFn, ToNHWCFn, WeightPack, _stream)
 
 
@@ -226,11 +226,12 @@ class GEGLU(nn.Module):
 
     def forward(self, x):
         pk = self.proj.pack
-        if (not torch.is_grad_enabled() and isinstance(self.proj, HipLinear) and pk.w16 is not None
-                and pk.k % 64 == 0 and (pk.n // 2) % 80 == 0):
-            # inference: the gate is applied in the GEMM epilogue; the [M][8C] pre-activation never reaches HBM
-            y = ops.gemm_geglu(x.reshape(-1, x.shape[-1]), pk.w16.view(pk.n, pk.k), self.proj.bias)
-            return y.view(*x.shape[:-1], pk.n // 2)
+        if isinstance(self.proj, HipLinear) and pk.w16 is not None and pk.k % 64 == 0 and (pk.n // 2) % 80 == 0:
+            # the gate is applied in the GEMM epilogue
+            if not torch.is_grad_enabled():         # inference: the [M][8C] pre-activation never reaches HBM
+                y = ops.gemm_geglu(x.reshape(-1, x.shape[-1]), pk.w16.view(pk.n, pk.k), self.proj.bias)
+                return y.view(*x.shape[:-1], pk.n // 2)
+            return GegluLinearFn.apply(x, pk, self.proj.bias, self.proj.weight)
         return GegluFn.apply(self.proj(x))
 
 

@@ -60,11 +60,13 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
 int mi355_conv2d_down_asym_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, void* out,
                                 const float* bias, void* workspace, size_t workspace_bytes, void* stream);
 
-/* GEGLU feed-forward input projection with the gate in the epilogue (inference path of the transformer block's
- * `ff.net[0]`, reached through image_generator.py:93-95): Bw [2F][K] = hidden rows then gate rows, bias [2F] or
- * NULL, out[M][F] = (A.Bw_h^T + b_h) * gelu_erf(A.Bw_g^T + b_g).  F a multiple of 80, K of 64. */
+/* GEGLU feed-forward input projection with the gate in the epilogue (the transformer block's `ff.net[0]`, reached
+ * through image_generator.py:93-95 and :124): Bw [2F][K] = hidden rows then gate rows, bias [2F] or NULL,
+ * out[M][F] = (A.Bw_h^T + b_h) * gelu_erf(A.Bw_g^T + b_g).  F a multiple of 80, K of 64.
+ * preact (optional, bf16 [M][2F]): receives the pre-activation (hidden | gate) a backward pass needs; the gate is
+ * then applied to those rounded values. */
 int mi355_gemm_geglu_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int F, int K, void* out, int ldo,
-                          const float* bias, void* stream);
+                          const float* bias, void* preact, void* stream);
 
 /* Implicit-GEMM convolution, NHWC bf16.  x [B][H][W][C]; w [Cout][k][k][C]; out [B][Ho][Wo][Cout].
  * ksize 1|3 (padding k/2), stride 1|2; ups=1 reads x through a nearest 2x upsample; dil=1 reads x
