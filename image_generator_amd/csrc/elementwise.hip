@@ -297,13 +297,27 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
+__global__ __launch_bounds__(256) void sumsq_bf16_kernel(const bf16_t* __restrict__ g, float* __restrict__ out, size_t n8) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *(const bf16x8*)(g + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[e] * (float)v[e];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
 // hyper (device floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=bias_corr1 [6]=bias_corr2
 //                        [7]=max_grad_norm (<=0: no clipping) [8]=grad pre-scale (e.g. 1/world)
 // state (device floats): [0]=sum of squared grads (input) ; [1]=skip flag output (1 when non-finite)
-template <int U, bool NT>
-__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// G16: the gradients are bf16 (the all-reduced staging buffer of a data-parallel step, read without unpacking)
+template <int U, bool NT, bool G16 = false>
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const void* __restrict__ gptr, float* __restrict__ m,
                              float* __restrict__ v, bf16_t* __restrict__ p_bf16, const float* __restrict__ hyper,
                              const float* __restrict__ state, size_t n) {
+    const float* g = (const float*)gptr;
+    const bf16_t* g16 = (const bf16_t*)gptr;
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6];
     const float maxn = hyper[7], pre = hyper[8];
     const float gnorm = sqrtf(state[0]) * pre;
@@ -320,13 +334,18 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
         for (int u = 0; u < U; ++u) {
             const size_t i = i0 + u * stride;
             if (i < n4) {
+                if (G16) {
+                    const bf16x4 t = __builtin_nontemporal_load((const bf16x4*)(g16 + i * 4));
+                    gv[u] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+                }
                 if (NT) {
                     pv[u] = __builtin_nontemporal_load((const f32x4*)(p + i * 4));
-                    gv[u] = __builtin_nontemporal_load((const f32x4*)(g + i * 4));
+                    if (!G16) gv[u] = __builtin_nontemporal_load((const f32x4*)(g + i * 4));
                     mv[u] = __builtin_nontemporal_load((const f32x4*)(m + i * 4));
                     vv[u] = __builtin_nontemporal_load((const f32x4*)(v + i * 4));
                 } else {
-                    pv[u] = *(const f32x4*)(p + i * 4); gv[u] = *(const f32x4*)(g + i * 4);
+                    pv[u] = *(const f32x4*)(p + i * 4);
+                    if (!G16) gv[u] = *(const f32x4*)(g + i * 4);
                     mv[u] = *(const f32x4*)(m + i * 4); vv[u] = *(const f32x4*)(v + i * 4);
                 }
             }
@@ -757,6 +776,13 @@ int mi355_sumsq_f32(const float* g, float* out, long long n, void* stream) {
     hipLaunchKernelGGL(sumsq_kernel, dim3(GRID_FOR(n / 4 + 1, 1024)), dim3(256), 0, ST, g, out, (size_t)n);
     return mi355_check_launch("sumsq");
 }
+int mi355_sumsq_bf16(const void* g, float* out, long long n, void* stream) {
+    if (!g || !out || (n & 7)) return mi355_fail(MI355_ERR_ARG, "sumsq_bf16: null pointer or n not a multiple of 8");
+    if (((uintptr_t)g) & 15) return mi355_fail(MI355_ERR_ARG, "sumsq_bf16: buffer must be 16-byte aligned");
+    ProfScope prof(FAM_ELEM, ST, (double)n * 2);
+    hipLaunchKernelGGL(sumsq_bf16_kernel, dim3(GRID_FOR(n / 8 + 1, 1024)), dim3(256), 0, ST, (const bf16_t*)g, out, (size_t)n / 8);
+    return mi355_check_launch("sumsq_bf16");
+}
 int mi355_zero_f32(float* p, long long n, void* stream) {
     if (!p) return mi355_fail(MI355_ERR_ARG, "zero: null pointer");
     if (((uintptr_t)p) & 15) return mi355_fail(MI355_ERR_ARG, "zero: buffer must be 16-byte aligned");
@@ -776,8 +802,19 @@ int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16,
     // 4 consecutive 4 KB runs per block and non-temporal accesses: 5.5 TB/s over the 30 B/parameter of traffic
     constexpr int U = 4;
     hipLaunchKernelGGL((adamw_kernel<U, true>), dim3((unsigned)(((size_t)n / 4 + 256 * U - 1) / (256 * U))), dim3(256), 0, ST,
-                       p, g, m, v, (bf16_t*)p_bf16, hyper, state, (size_t)n);
+                       p, (const void*)g, m, v, (bf16_t*)p_bf16, hyper, state, (size_t)n);
     return mi355_check_launch("adamw");
+}
+// Same step with bf16 gradients (8-byte aligned, n a multiple of 4).
+int mi355_adamw_step_g16(float* p, const void* g16, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
+                         long long n, void* stream) {
+    if (!p || !g16 || !m || !v || !hyper || !state) return mi355_fail(MI355_ERR_ARG, "adamw_g16: null pointer");
+    if ((n & 3) || ((uintptr_t)g16 & 7)) return mi355_fail(MI355_ERR_ARG, "adamw_g16: n must be a multiple of 4, gradients 8-byte aligned");
+    ProfScope prof(FAM_ELEM, ST, (double)n * 28);
+    constexpr int U = 4;
+    hipLaunchKernelGGL((adamw_kernel<U, true, true>), dim3((unsigned)(((size_t)n / 4 + 256 * U - 1) / (256 * U))), dim3(256), 0, ST,
+                       p, g16, m, v, (bf16_t*)p_bf16, hyper, state, (size_t)n);
+    return mi355_check_launch("adamw_g16");
 }
 
 // scratch floats: 2*B*D (normalised copies) + 2*B (norms) + B*B (logits/dlogits) + 2*B (lse)

@@ -53,7 +53,7 @@ class GradBucketReducer:
     makes the compute stream wait for all communication.
     """
 
-    def __init__(self, flat_grad, n_big, grad_packs, group=None, bucket_mb=64):
+    def __init__(self, flat_grad, n_big, grad_packs, group=None, bucket_mb=64, unpack=False):
         """flat_grad: fp32 gradient buffer; [0, n_big) holds the GEMM weights, the rest small parameters;
         grad_packs: (offset, numel, pack) per layer, `pack.on_grad_ready` is installed here."""
         self.group = group
@@ -77,8 +77,10 @@ class GradBucketReducer:
         self.tail = (n_big, self.flat_grad.numel())
         self.active = self.world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1"
         self._counts = []
-        self._stage = [torch.empty(e - s, dtype=BF16, device=self.device) for s, e, _ in self.buckets]
-        self._tail_stage = torch.empty(self.tail[1] - self.tail[0], dtype=BF16, device=self.device)
+        self.unpack = unpack
+        self.stage_all = torch.zeros(self.flat_grad.numel(), dtype=BF16, device=self.device)
+        self._stage = [self.stage_all[s:e] for s, e, _ in self.buckets]
+        self._tail_stage = self.stage_all[self.tail[0]:self.tail[1]]
         for bi, (s, e, pks) in enumerate(self.buckets):
             for pk in pks:
                 pk.on_grad_ready = (lambda b=bi: self._ready(b))
@@ -96,11 +98,13 @@ class GradBucketReducer:
                 self.comm_stream.wait_event(ev)
                 stage.copy_(g)                                   # fp32 -> bf16 pack
                 dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
-                g.copy_(stage)                                   # back to fp32 (the optimizer divides by world)
+                if self.unpack:
+                    g.copy_(stage)                               # back to fp32 (the optimizer divides by world)
         else:
             stage.copy_(g)
             dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
-            g.copy_(stage)
+            if self.unpack:
+                g.copy_(stage)
 
     def _ready(self, b):
         self._counts[b] -= 1
@@ -156,20 +160,30 @@ class FusedAdamW:
         h[7], h[8] = self.max_norm if self.max_norm else 0.0, grad_prescale
         self.hyper.copy_(h, non_blocking=True)
 
-    def apply(self):
-        """The device-side part of the step (capturable)."""
+    def apply(self, grad16=None):
+        """The device-side part of the step (capturable).  grad16: bf16 gradients laid out like the flat buffer (the
+        all-reduced staging buffer of a data-parallel step) to use instead of the fp32 ones."""
         s = _stream()
         n = self.flat.numel()
         check(lib.mi355_zero_f32(self.state.data_ptr(), 2, s), "zero")
-        check(lib.mi355_sumsq_f32(self.grad.data_ptr(), self.state.data_ptr(), n, s), "sumsq")
-        check(lib.mi355_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                   self.flat16.data_ptr(), self.hyper.data_ptr(), self.state.data_ptr(), n, s), "adamw")
+        if grad16 is not None and n % 8 == 0:
+            assert grad16.numel() == n and grad16.dtype == BF16
+            check(lib.mi355_sumsq_bf16(grad16.data_ptr(), self.state.data_ptr(), n, s), "sumsq_bf16")
+            check(lib.mi355_adamw_step_g16(self.flat.data_ptr(), grad16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                           self.flat16.data_ptr(), self.hyper.data_ptr(), self.state.data_ptr(), n, s),
+                  "adamw_g16")
+        else:
+            if grad16 is not None:
+                self.grad.copy_(grad16)
+            check(lib.mi355_sumsq_f32(self.grad.data_ptr(), self.state.data_ptr(), n, s), "sumsq")
+            check(lib.mi355_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                       self.flat16.data_ptr(), self.hyper.data_ptr(), self.state.data_ptr(), n, s), "adamw")
         if not self.frozen_base:          # a frozen base keeps its operand copies; the adapters are read as fp32 masters
             self.unet.refresh_operands(cast=False)
 
-    def step(self, lr=None, grad_prescale=1.0):
+    def step(self, lr=None, grad_prescale=1.0, grad16=None):
         self.set_hyper(lr, grad_prescale)
-        self.apply()
+        self.apply(grad16)
 
     def grad_norm(self):
         """Host read of the last step's pre-clip global gradient norm (synchronises)."""
@@ -275,7 +289,8 @@ class DenoiserTrainer:
         if self._graph is not None:
             return self._replay(latents, noise, t, ctx, lr)
         loss = self.forward_backward(latents, noise, t, ctx)
-        self.opt.step(lr=lr, grad_prescale=1.0 / self.world)
+        reduced = self.reducer.stage_all if (self.reducer is not None and self.reducer.active) else None
+        self.opt.step(lr=lr, grad_prescale=1.0 / self.world, grad16=reduced)
         self.step_count += 1
         return loss
 

@@ -174,6 +174,11 @@ int mi355_zero_f32(float* p, long long n, void* stream);
 int mi355_zero_ranges(const long long* table, int n, void* stream);
 int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
                      long long n, void* stream);
+/* The same two steps on bf16 gradients: a data-parallel step feeds the optimizer the all-reduced bf16 staging
+ * buffer directly instead of unpacking it to fp32 first (n a multiple of 8 for the norm, of 4 for the update). */
+int mi355_sumsq_bf16(const void* g16, float* out, long long n, void* stream);
+int mi355_adamw_step_g16(float* p, const void* g16, float* m, float* v, void* p_bf16, const float* hyper,
+                         const float* state, long long n, void* stream);
 
 /* ---- LoRA (lora.py:23-24): rank-r side products around the fused GEMM epilogue --------------------*/
 /* t = x A^T (fp32 [M][R]; A may be several adapters' factors stacked, R <= 16).  t16 (optional): bf16 copy

@@ -29,9 +29,11 @@ def _worker(rank, world, port, out):
     for n in sizes:
         packs.append((off, n, _Pack()))
         off += n
-    red = GradBucketReducer(flat, n_big, packs, bucket_mb=0.03)     # ~8k floats per bucket -> several buckets
-    assert len(red.buckets) >= 2
     for step in range(2):
+        # step 0: the reduced gradients stay in the bf16 staging buffer (what the fused optimizer reads);
+        # step 1: `unpack=True` also writes them back into the fp32 buffer
+        red = GradBucketReducer(flat, n_big, packs, bucket_mb=0.03, unpack=step == 1)   # ~8k floats per bucket
+        assert len(red.buckets) >= 2
         g = torch.Generator().manual_seed(100 * step + rank)
         local = torch.randn(n_big + tail, generator=g)
         flat[n_big:] = local[n_big:]
@@ -40,7 +42,9 @@ def _worker(rank, world, port, out):
             flat[o:o + n] = local[o:o + n]
             pk.on_grad_ready()
         red.finish()
-        out[(rank, step)] = flat.clone()
+        out[(rank, step)] = flat.clone() if step == 1 else red.stage_all.float()
+        if step == 0:
+            assert torch.equal(flat, local)                           # the fp32 buffer keeps the local gradients
     dist.destroy_process_group()
 
 
