@@ -49,6 +49,7 @@ struct GemmArgs {
     float lora_alpha;
     float* partial;          // split-K slabs [splitk][M][N] fp32
     int splitk, kt_per_split;
+    int bm;                  // rows per tile (128, or 256 for large grids on the LDS-DMA kernel)
     int geglu;               // fused GEGLU: N = 2F weight rows (hidden | gate), out [M][F] = h * gelu(g)
     bf16_t* preact;          // geglu only, optional: [M][2F] pre-activation (hidden | gate) kept for the backward pass
     int tiles_m, tiles_n;
@@ -89,7 +90,7 @@ __device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, floa
     }
 }
 
-template <int BN, int TM, int TN, int NTHREADS = 256>
+template <int BN, int TM, int TN, int NTHREADS = 256, int BM = 128>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], char* smem, int m0, int n0,
                                               int split, int wm0, int wn0, int wave, int tid, int fr, int fq) {
     constexpr int EP_LD = BN + 4;
@@ -111,17 +112,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 
     // ---- epilogue through LDS, 64 rows at a time
     float* ep = (float*)smem;
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < BM / 64; ++h) {
         __syncthreads();
-        const int wrow = wm0 - h * 64;              // this wave's first row inside the 64-row half, if it is in it
-        if (wrow >= 0 && wrow < 64) {
+        // the wave stages those of its 16-row blocks that lie inside this 64-row group
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int wrow = wm0 + i * 16 - h * 64;
+            if (wrow >= 0 && wrow < 64) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        ep[(wrow + i * 16 + fq * 4 + r) * EP_LD + wn0 + j * 16 + fr] = acc[i][j][r];
+                        ep[(wrow + fq * 4 + r) * EP_LD + wn0 + j * 16 + fr] = acc[i][j][r];
+            }
         }
         __syncthreads();
         constexpr int NC = BN / 8;
@@ -377,10 +380,13 @@ constexpr int OOB_OFF = (int)0x80000000;
 // NW = 4: 2x2 waves of 64 x BN/2, two workgroups per CU.  NW = 8: 4x2 waves of 32 x BN/2 on the same tile, for
 // grids of at most one workgroup per CU: a lone 4-wave workgroup has one wave per SIMD, whose DMA issue, LDS
 // reads and MFMAs serialise; eight waves give every SIMD a second wave to overlap them with.
-template <int BN, int AMODE, int NW = 4>
+// BM: rows per tile.  (256 rows with 8 waves as ONE workgroup per CU measured 15 % slower than two 128-row
+// workgroups: its waves run barrier-locked, so DMA issue and MFMA phases never overlap.  Large grids use
+// gemm_wide_kernel instead.)
+template <int BN, int AMODE, int NW = 4, int BM = 128>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the body uses device-only buffer-resource builtins
-    constexpr int BM = 128, BK = 64;
+    constexpr int BK = 64;
     constexpr int WM = BM / (NW / 2), WN = BN / 2;
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int A_P = BM / 8 / NW;                     // 1 KiB pieces (8 rows x 128 B) per wave
@@ -518,7 +524,147 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BN, TM, TN, NW * 64>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+    gemm_epilogue<BN, TM, TN, NW * 64, BM>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide-tile variant for large grids: 256 x 160 output tile, 32-deep k-steps, 4 waves of 128 x 80, two
+// workgroups per CU.  Every operand byte enters the CU through the vector-memory path (64 B/clk), and the 128 x 160
+// tile keeps that path ~90 % busy at 40 % MFMA utilisation (72 KB per 1280 MFMA cycles); this tile moves 28 % fewer
+// bytes per FLOP through it and through LDS (13 instead of 18 fragment reads per 40 MFMAs).
+// A 1 KiB DMA piece is 16 rows x 32 k = exactly one 16x16x32 MFMA operand fragment: lane l fetches row l/4,
+// 16-byte k-chunk (l%4) ^ F[l/16], and the fragment read of lane (row fr, chunk fq) is slot fr*4 + (fq ^ F[fr/4]);
+// F = {0,2,3,1} makes the four 16-lane groups of ds_read_b128 hit 16 distinct 16-byte bank groups each.
+// ---------------------------------------------------------------------------------------------
+template <int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 256, BN = 160, BK = 32, NW = 4;
+    constexpr int TM = 8, TN = 5;
+    constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16, PIECES = A_PIECES + B_PIECES;     // 16 + 10
+    constexpr int NP = (PIECES + NW - 1) / NW;                                               // 7 per wave (waves 2,3: 6)
+    constexpr int STAGE = PIECES * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 80;
+
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % p.tiles_n;
+    const int tile_m = lid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nkt = p.K / BK;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw, 0, b_bytes, 0x00020000);
+
+    const int prow = lane >> 2;                                            // row inside the 16-row piece
+    const int kc = (lane & 3) ^ ((0x78 >> (2 * (lane >> 4))) & 3);         // k-chunk fetched by this lane
+    // piece q of this wave is tile piece wave + 4*q: an A piece while < 16, else B piece (index - 16)
+    int voff[NP], iy0[NP], ix0[NP];
+    const int pad = p.g.pad;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pc = wave + NW * q;
+        iy0[q] = ix0[q] = 0;
+        if (pc < A_PIECES) {
+            const int m = m0 + pc * 16 + prow;
+            const bool ok = m < p.M;
+            if constexpr (AMODE == AMODE_DENSE) {
+                voff[q] = ok ? (m * p.lda + kc * 8) * 2 : OOB_OFF;
+            } else {
+                const int mm = ok ? m : 0;
+                const int ox = mm % p.g.Wo;
+                const int t = mm / p.g.Wo;
+                const int oy = t % p.g.Ho;
+                const int b = t / p.g.Ho;
+                voff[q] = ok ? b * p.g.H * p.g.W : -1;
+                iy0[q] = oy * p.g.stride - pad;
+                ix0[q] = ox * p.g.stride - pad;
+            }
+        } else if (pc < PIECES) {
+            const int nl = (pc - A_PIECES) * 16 + prow;
+            int n = n0 + nl;
+            if (p.geglu) {                   // first half of the tile: hidden rows, second half: the matching gate rows
+                const int F = p.N >> 1, f0 = tile_n * (BN / 2);
+                n = nl < BN / 2 ? f0 + nl : F + f0 + nl - BN / 2;
+                if (f0 + (nl < BN / 2 ? nl : nl - BN / 2) >= F) n = p.N;
+            }
+            voff[q] = n < p.N ? (n * p.ldb + kc * 8) * 2 : OOB_OFF;
+        } else {
+            voff[q] = OOB_OFF;
+        }
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char* base = smem + stage * STAGE;
+        const int soffb = kt * (BK * 2);
+        int soffa = soffb, ky = 0, kx = 0;
+        if constexpr (AMODE != AMODE_DENSE) {
+            const int kk = kt * BK;
+            const int tap = kk / p.g.C;
+            soffa = (kk - tap * p.g.C) * 2;
+            if (p.g.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int pc = wave + NW * q;
+            if (pc >= PIECES) continue;
+            if (pc < A_PIECES) {
+                int v = voff[q];
+                if constexpr (AMODE != AMODE_DENSE) {
+                    int sy = iy0[q] + ky, sx = ix0[q] + kx;
+                    bool ok = voff[q] >= 0 && sy >= 0 && sx >= 0;
+                    if (p.g.dil) {
+                        ok = ok && !((sy | sx) & 1);
+                        sy >>= 1; sx >>= 1;
+                    } else if (p.g.ups) {
+                        sy >>= 1; sx >>= 1;
+                    }
+                    ok = ok && sy < p.g.H && sx < p.g.W;
+                    v = ok ? ((voff[q] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + pc * 1024), 16, v, soffa, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base + pc * 1024), 16, voff[q], soffb, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rd = (fr * 4 + (fq ^ ((0x78 >> (2 * (fr >> 2))) & 3))) * 16;       // this lane's slot inside a fragment piece
+    issue(0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nkt) issue(kt + 1, cur ^ 1);
+        const char* As = smem + cur * STAGE + (wm0 >> 4) * 1024 + rd;
+        const char* Bs = smem + cur * STAGE + (A_PIECES + wn0 / 16) * 1024 + rd;
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *(const bf16x8*)(Bs + j * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(As + i * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_epilogue<BN, TM, TN, 256, BM>(p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq);
 #endif
 }
 
@@ -578,6 +724,18 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n * a.splitk;
     hipLaunchKernelGGL((gemm_kernel<BN, AMODE>), dim3(grid), dim3(256), smem, s, a);
     return mi355_check_launch("gemm_kernel");
+}
+
+template <int AMODE>
+static int launch_gemm_wide(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
+    constexpr int smem = 2 * 26 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_wide_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_wide_kernel<AMODE>), dim3(a.tiles_m * a.tiles_n), dim3(256), smem, s, a, a_bytes, b_bytes);
+    return mi355_check_launch("gemm_wide_kernel");
 }
 
 // Split-K choice by a small cost model (all in microseconds): the grid runs in waves of `capacity`
@@ -661,7 +819,20 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     const bool dma_ok = !force_v1 && a.K % 64 == 0 && amode != AMODE_CONV_GENERIC && a_sz < 2.0e9 && b_sz < 2.0e9 &&
                         (double)a.M * (amode == AMODE_DENSE ? a.lda : 1) < 1.0e9;
     if (a.geglu && !dma_ok) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_geglu: needs K %% 64 == 0 and operands < 2 GB");
-    if (dma_ok) {
+    a.bm = 128;
+    {   // 256-row tiles when the grid still gives every CU its two workgroups
+        static const int bm256 = getenv("MI355_GEMM_BM256") ? atoi(getenv("MI355_GEMM_BM256")) : 1;
+        const int t256 = ((a.M + 255) / 256) * a.tiles_n;
+        static const int wide_min = getenv("MI355_GEMM_WIDE_MIN") ? atoi(getenv("MI355_GEMM_WIDE_MIN")) : 512;
+        if (bm256 && dma_ok && bn == 160 && sk == 1 && t256 >= wide_min) {       // at least two workgroups per CU
+            a.bm = 256;
+            a.tiles_m = (a.M + 255) / 256;
+        }
+    }
+    if (dma_ok && a.bm == 256) {
+        const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
+        rc = amode == AMODE_DENSE ? launch_gemm_wide<AMODE_DENSE>(a, ab, bb, s) : launch_gemm_wide<AMODE_CONV_FAST>(a, ab, bb, s);
+    } else if (dma_ok) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
 #define DISPATCH_DMA(BN) (amode == AMODE_DENSE ? launch_gemm_dma<BN, AMODE_DENSE>(a, ab, bb, s) \
                                                : launch_gemm_dma<BN, AMODE_CONV_FAST>(a, ab, bb, s))

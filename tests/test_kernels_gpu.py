@@ -417,3 +417,50 @@ def test_gemm_geglu_fused_epilogue():
             pre = x.float() @ w.float().t() + (0 if bias is None else bias)
             ref = pre[:, :Fh] * F.gelu(pre[:, Fh:])
             close(y, ref, 2 ** -7, 2 ** -7 * float(ref.abs().max()), f"geglu M{M} K{K} F{Fh}")
+
+
+def test_wide_tile_gemm_paths():
+    """Grids of 512+ tiles of 256 x 160 take the wide-tile kernel (dense, implicit-GEMM conv, fused GEGLU): ragged M,
+    bias + residual + row bias, every conv addressing mode, against fp32 torch on the GPU (CPU would take minutes)."""
+    from image_generator_amd import ops
+    d = dev()
+    # dense: M not a multiple of 256, N = 2560, K = 320
+    M, N, K = 256 * 33 - 24, 2560, 320
+    a, w = rnd(M, K, seed=11).to(d), rnd(N, K, scale=K ** -0.5, seed=12).to(d)
+    bias, res = torch.randn(N, generator=torch.Generator().manual_seed(13)).to(d), rnd(M, N, seed=14).to(d)
+    out = ops.gemm(a, w, bias=bias, residual=res)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    assert rel_l2(out, ref) < 4e-3
+    close(out, ref, 2 ** -7, 3e-2, "wide dense")
+    # convolution 3x3 (padding taps), row bias per sample, 64 channels in: B*H*W = 34*32*32 pixels x 640 outputs
+    B, H, C, Co = 34, 32, 64, 640
+    x, wc = rnd(B, H, H, C, seed=15).to(d), rnd(Co, 3, 3, C, scale=(9 * C) ** -0.5, seed=16).to(d)
+    rb = torch.randn(B, Co, generator=torch.Generator().manual_seed(17)).to(d)
+    y = ops.conv2d(x, wc, Co, 3, rowbias=rb)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wc.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1) + rb[:, None, None, :]
+    assert rel_l2(y, ref) < 4e-3
+    # nearest-2x upsampled input and the zero-dilated (data-gradient of stride 2) input
+    x2 = rnd(B, 16, 16, C, seed=18).to(d)
+    y = ops.conv2d(x2, wc, Co, 3, ups=True)
+    ref = F.conv2d(F.interpolate(x2.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"),
+                   wc.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert rel_l2(y, ref) < 4e-3
+    y = ops.conv2d(x2, wc, Co, 3, dil=True, out_hw=(32, 32))
+    xd = torch.zeros(B, C, 32, 32, device=d)
+    xd[:, :, ::2, ::2] = x2.float().permute(0, 3, 1, 2)
+    ref = F.conv2d(xd, wc.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert rel_l2(y, ref) < 4e-3
+    # stride 2
+    x3 = rnd(B, 64, 64, C, seed=19).to(d)
+    y = ops.conv2d(x3, wc, Co, 3, stride=2)
+    ref = F.conv2d(x3.float().permute(0, 3, 1, 2), wc.float().permute(0, 3, 1, 2), stride=2, padding=1).permute(0, 2, 3, 1)
+    assert rel_l2(y, ref) < 4e-3
+    # fused GEGLU with the stored pre-activation
+    M, C = 256 * 36, 320
+    a, w = rnd(M, C, seed=20).to(d), rnd(8 * C, C, scale=C ** -0.5, seed=21).to(d)
+    bias = torch.randn(8 * C, generator=torch.Generator().manual_seed(22)).to(d)
+    y, pre = ops.gemm_geglu(a, w, bias, keep_preact=True)
+    pr = a.float() @ w.float().t() + bias
+    assert rel_l2(pre, pr) < 4e-3
+    ref = pr[:, :4 * C] * F.gelu(pr[:, 4 * C:])
+    assert rel_l2(y, ref) < 6e-3
