@@ -464,3 +464,83 @@ def test_wide_tile_gemm_paths():
     assert rel_l2(pre, pr) < 4e-3
     ref = pr[:, :4 * C] * F.gelu(pr[:, 4 * C:])
     assert rel_l2(y, ref) < 6e-3
+
+
+def test_norm_passthrough_and_frozen_affine():
+    """Norm Functions in pass-through form: y = norm(x), x' = x; the gradient of the branch on x' is added inside
+    the backward kernel (dx = norm_bwd(dy) + dpass).  Frozen affine parameters: same dx, no parameter gradients."""
+    from image_generator_amd.ops import GroupNormFn, LayerNormFn
+    d = dev()
+    x = (rnd(2, 8, 8, 64, seed=31).float() * 1.3 + 0.2).to(BF)
+    gamma, beta = torch.randn(64) * 0.2 + 1.0, torch.randn(64) * 0.1
+    dy, dp = rnd(2, 8, 8, 64, seed=32), rnd(2, 8, 8, 64, seed=33)
+    xr, gr, br = x.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.silu(F.group_norm(xr.permute(0, 3, 1, 2), 8, gr, br, 1e-5)).permute(0, 2, 3, 1)
+    (ref * dy.float()).sum().backward()
+    want_dx = xr.grad + dp.float()
+    for frozen in (False, True):
+        xg = x.to(d).requires_grad_(True)
+        gg, bg = gamma.to(d).requires_grad_(not frozen), beta.to(d).requires_grad_(not frozen)
+        y, xp = GroupNormFn.apply(xg, gg, bg, 8, 1e-5, True, None, True)
+        assert xp.data_ptr() == xg.data_ptr()
+        torch.autograd.backward([y, xp], [dy.to(d), dp.to(d)])
+        assert rel_l2(xg.grad, want_dx) < 1e-2
+        if frozen:
+            assert gg.grad is None and bg.grad is None
+        else:
+            assert rel_l2(gg.grad, gr.grad) < 2e-3 and rel_l2(bg.grad, br.grad) < 2e-3
+    x2, dy2, dp2 = rnd(100, 320, seed=34), rnd(100, 320, seed=35), rnd(100, 320, seed=36)
+    g2, b2 = torch.randn(320) * 0.2 + 1.0, torch.randn(320) * 0.1
+    xr = x2.float().requires_grad_(True)
+    (F.layer_norm(xr, (320,), g2, b2, 1e-5) * dy2.float()).sum().backward()
+    for frozen in (False, True):
+        xg = x2.to(d).requires_grad_(True)
+        gg, bg = g2.to(d).requires_grad_(not frozen), b2.to(d).requires_grad_(not frozen)
+        y, xp = LayerNormFn.apply(xg, gg, bg, 1e-5, None, True)
+        torch.autograd.backward([y, xp], [dy2.to(d), dp2.to(d)])
+        assert rel_l2(xg.grad, xr.grad + dp2.float()) < 1e-2
+        assert (gg.grad is None) == frozen
+
+
+def test_small_utility_entry_points():
+    """zero_ranges, copy2d_batched and the bf16-gradient optimizer variants against their obvious definitions."""
+    from image_generator_amd.ops import lib, check, _stream
+    d = dev()
+    buf = torch.ones(4096, device=d)
+    table = torch.tensor([buf.data_ptr() + 4 * 16, 4 * 64, buf.data_ptr() + 4 * 1024, 4 * 2000], dtype=torch.int64, device=d)
+    check(lib.mi355_zero_ranges(table.data_ptr(), 2, _stream()))
+    want = torch.ones(4096)
+    want[16:80] = 0
+    want[1024:3024] = 0
+    assert torch.equal(buf.cpu(), want)
+    src = torch.arange(40 * 8, dtype=torch.float32, device=d).view(40, 8)
+    dst = torch.full((40, 4), -1.0, device=d)
+    src2, dst2 = torch.randn(8, 96, device=d), torch.zeros(4, 96, device=d)
+    t2 = torch.tensor([src.data_ptr() + 4 * 4, dst.data_ptr(), 40, 4, 8, 4,
+                       src2.data_ptr(), dst2.data_ptr(), 4, 96, 96, 96], dtype=torch.int64, device=d)
+    check(lib.mi355_copy2d_f32_batched(t2.data_ptr(), 2, _stream()))
+    assert torch.equal(dst, src[:, 4:8]) and torch.equal(dst2, src2[:4])
+    # AdamW fed with bf16 gradients == AdamW fed with the same values in fp32
+    n = 8192
+    g16 = (torch.randn(n) * 2).to(BF).to(d)
+    outs = []
+    for use16 in (False, True):
+        torch.manual_seed(5)
+        p = torch.randn(n, device=d)
+        m, v = torch.zeros(n, device=d), torch.zeros(n, device=d)
+        p16 = torch.empty(n, dtype=BF, device=d)
+        state = torch.zeros(2, device=d)
+        hyper = torch.tensor([1e-2, 0.9, 0.999, 1e-8, 0.01, 0.1, 0.001, 1.0, 0.5], device=d)
+        if use16:
+            check(lib.mi355_sumsq_bf16(g16.data_ptr(), state.data_ptr(), n, _stream()))
+            check(lib.mi355_adamw_step_g16(p.data_ptr(), g16.data_ptr(), m.data_ptr(), v.data_ptr(), p16.data_ptr(),
+                                           hyper.data_ptr(), state.data_ptr(), n, _stream()))
+        else:
+            g32 = g16.float()
+            check(lib.mi355_sumsq_f32(g32.data_ptr(), state.data_ptr(), n, _stream()))
+            check(lib.mi355_adamw_step(p.data_ptr(), g32.data_ptr(), m.data_ptr(), v.data_ptr(), p16.data_ptr(),
+                                       hyper.data_ptr(), state.data_ptr(), n, _stream()))
+        outs.append((p.cpu(), m.cpu(), v.cpu(), p16.float().cpu(), float(state[0])))
+    assert abs(outs[0][4] - outs[1][4]) <= 1e-5 * outs[0][4]
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
