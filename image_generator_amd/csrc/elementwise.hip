@@ -660,6 +660,26 @@ __global__ __launch_bounds__(256) void copy2d_batched_kernel(const long long* __
     }
 }
 
+// Per-step bf16 operands of the adapters' skinny GEMMs, one launch for all of them.  Record = 6 int64:
+//   {0, src fp32, dst bf16, n, -, -}          dst[i] = bf16(src[i])                      (stacked A factors, row-major)
+//   {1, src fp32 [C][r], dst bf16, C, r, ld}   dst[q * ld + c] = bf16(src[c * r + q])      (one adapter's B, transposed into
+//                                                                                         its block of the [W][N] operand)
+__global__ __launch_bounds__(256) void lora_pack_kernel(const long long* __restrict__ table) {
+    const long long* e = table + 6 * blockIdx.y;
+    const float* src = (const float*)e[1];
+    bf16_t* dst = (bf16_t*)e[2];
+    if (e[0] == 0) {
+        const long long n = e[3];
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (bf16_t)src[i];
+    } else {
+        const long long C = e[3], r = e[4], ld = e[5];
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < C * r; i += (long long)gridDim.x * 256) {
+            const long long q = i / C, c = i - q * C;
+            dst[q * ld + c] = (bf16_t)src[c * r + q];
+        }
+    }
+}
+
 extern "C" {
 
 #define ST ((hipStream_t)stream)
@@ -878,6 +898,11 @@ int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, in
         hipLaunchKernelGGL(lora_outer_kernel<false>, dim3(gx, gy), dim3(256), smem, ST, (const bf16_t*)y, t, out, M, C, R, scale,
                            rows, NC, RL, flags & 1);
     return mi355_check_launch("lora_outer");
+}
+int mi355_lora_pack(const long long* table, int n, void* stream) {
+    if (!table || n < 1) return mi355_fail(MI355_ERR_ARG, "lora_pack: bad arguments");
+    hipLaunchKernelGGL(lora_pack_kernel, dim3(8, n), dim3(256), 0, ST, table);
+    return mi355_check_launch("lora_pack");
 }
 // Batched strided 2-D copy of fp32 blocks: table holds n records {src, dst, rows, cols, src_ld, dst_ld} (int64).
 int mi355_copy2d_f32_batched(const long long* table, int n, void* stream) {

@@ -46,6 +46,7 @@ struct GemmArgs {
     int lora_ldt;            // row stride of lora_t (floats)
     int lora_seg;            // > 0: outputs per row-stacked adapter (each reads its own r columns of lora_t)
     int lora_rmajor;         // lora_b is [r][N] instead of [N][r]
+    int lora_t_bf16;         // lora_t points at bf16 [M][lora_ldt], lora_ldt 8 or 16
     float lora_alpha;
     float* partial;          // split-K slabs [splitk][M][N] fp32
     int splitk, kt_per_split;
@@ -64,28 +65,50 @@ __device__ __forceinline__ float gemm_gelu_erf(float x) { return gelu_erf_f(x); 
 // Low-rank term of 8 adjacent outputs: v[e] += lora_alpha * sum_r t[m][r] * b(n + e, r).  `lora_seg` > 0: the columns
 // are row-stacked adapters of `lora_seg` outputs each and adapter s reads t[m][s*r .. s*r + r) (fused projections).
 __device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, float (&v)[8]) {
-    const float* t = p.lora_t + (size_t)m * p.lora_ldt + (p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0);
-    if (p.lora_rmajor) {                        // factors [r][N]: eight adjacent columns are two 16-byte loads per rank
-        for (int r = 0; r < p.lora_r; ++r) {
-            const float tv = t[r] * p.lora_alpha;
-            const float* bp = p.lora_b + (size_t)r * p.N + n;
-            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+    const int toff = p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0;
+    float tv[16];
+    if (p.lora_t_bf16) {                        // bf16 [M][ldt] (ldt = 8 or 16), e.g. the output of a skinny GEMM
+        const bf16_t* t = (const bf16_t*)p.lora_t + (size_t)m * p.lora_ldt;
+        const bf16x8 lo = *(const bf16x8*)t;
+        const bf16x8 hi = p.lora_ldt > 8 ? *(const bf16x8*)(t + 8) : lo;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += tv * b0[e]; v[4 + e] += tv * b1[e]; }
+        for (int r = 0; r < 8; ++r) { tv[r] = (float)lo[r]; tv[8 + r] = (float)hi[r]; }
+    } else {
+        const float* t = p.lora_t + (size_t)m * p.lora_ldt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tv[r] = r < p.lora_ldt ? t[r] : 0.f;
+    }
+    if (p.lora_rmajor) {                        // factors [r][N]: eight adjacent columns are two 16-byte loads per rank
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < p.lora_r) {
+                const float tr = tv[r] * p.lora_alpha;
+                const float* bp = p.lora_b + (size_t)r * p.N + n;
+                const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += tr * b0[e]; v[4 + e] += tr * b1[e]; }
+            }
         }
     } else if (p.lora_r == 4) {                 // factors [N][4]: one 16-byte load per column
-        const f32x4 tv = *(const f32x4*)t * p.lora_alpha;
+        float t4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // toff is 0, 4, 8 or 12: pick without dynamic register indexing
+            const float a = toff == 0 ? tv[r] : toff == 4 ? tv[4 + r] : toff == 8 ? tv[8 + r] : tv[12 + r];
+            t4[r] = a * p.lora_alpha;
+        }
         const f32x4* bp = (const f32x4*)(p.lora_b + (size_t)n * 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const f32x4 bv = bp[e];
-            v[e] += tv[0] * bv[0] + tv[1] * bv[1] + tv[2] * bv[2] + tv[3] * bv[3];
+            v[e] += t4[0] * bv[0] + t4[1] * bv[1] + t4[2] * bv[2] + t4[3] * bv[3];
         }
     } else {
+        const float* t = p.lora_t + (size_t)m * p.lora_ldt + toff;     // generic rank: fp32 factors only
         for (int r = 0; r < p.lora_r; ++r) {
-            const float tv = t[r] * p.lora_alpha;
+            const float tr = t[r] * p.lora_alpha;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += tv * p.lora_b[(size_t)(n + e) * p.lora_r + r];
+            for (int e = 0; e < 8; ++e) v[e] += tr * p.lora_b[(size_t)(n + e) * p.lora_r + r];
         }
     }
 }
@@ -668,6 +691,52 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM: out[M][W] = alpha * A[M][K] . Bw[W][K]^T with W = 8 or 16 (the rank-padded products of the LoRA
+// adapters: x A^T and dy B).  The tile kernels would spend a 128 x 64 tile, split-K slabs and a reduce launch on it;
+// here a workgroup owns 16 rows, its four waves take every fourth 32-deep k-step with both operands loaded straight
+// from global memory in MFMA layout (Bw is a few KB and stays in L1/L2), and the MFMA is issued with the operands
+// swapped so that a lane ends up with four adjacent outputs of one row - an 8-byte store, no LDS transpose.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Bw,
+                                                          bf16_t* __restrict__ out, int M, int K, float alpha) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int row = blockIdx.x * 16 + fr;
+    const bool row_ok = row < M, col_ok = fr < W;
+    const bf16_t* ap = A + (size_t)(row_ok ? row : 0) * lda + fq * 8;
+    const bf16_t* bp = Bw + (size_t)(col_ok ? fr : 0) * K + fq * 8;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nks = K >> 5;
+    int ks = wave;
+    for (; ks + 12 < nks; ks += 16) {               // four k-steps in flight per wave
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = row_ok ? *(const bf16x8*)(ap + (ks + 4 * u) * 32) : zero8;
+            b[u] = col_ok ? *(const bf16x8*)(bp + (ks + 4 * u) * 32) : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u], a[u], acc, 0, 0, 0);
+    }
+    for (; ks < nks; ks += 4) {
+        const bf16x8 a = row_ok ? *(const bf16x8*)(ap + ks * 32) : zero8;
+        const bf16x8 b = col_ok ? *(const bf16x8*)(bp + ks * 32) : zero8;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
+    }
+    // acc[r] = sum_k A[row fr][k] * Bw[4 fq + r][k] over this wave's k-steps
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && row_ok && 4 * fq < W) {
+        acc += red[0][lane] + red[1][lane] + red[2][lane];
+        bf16x4 o = {(bf16_t)(acc[0] * alpha), (bf16_t)(acc[1] * alpha), (bf16_t)(acc[2] * alpha), (bf16_t)(acc[3] * alpha)};
+        *(bf16x4*)(out + (size_t)row * W + 4 * fq) = o;
+    }
+}
+
 // Sums the split-K slabs and applies the same epilogue as the fused path.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int nc = p.N / 8;
@@ -873,19 +942,37 @@ size_t mi355_gemm_workspace_bytes(int M, int N) {
 int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
                     int out_fp32, const float* bias, const float* rowbias, int rowbias_div, int ld_rowbias,
                     const void* residual, int ldr, float alpha, const float* lora_t, int lora_ldt, const float* lora_b, int lora_r,
-                    int lora_seg, int lora_rmajor, float lora_alpha, void* workspace, size_t workspace_bytes, void* stream) {
+                    int lora_seg, int lora_rmajor, int lora_t_bf16, float lora_alpha, void* workspace, size_t workspace_bytes,
+                    void* stream) {
     if (!A || !Bw || !out) return mi355_fail(MI355_ERR_ARG, "gemm: null pointer");
-    if (lora_t && (!lora_b || lora_r < 1 || lora_ldt < lora_r || (lora_seg && (lora_seg & 7)) ||
-                   ((lora_r == 4 && !lora_rmajor) && (lora_ldt & 3))))
+    if (lora_t && (!lora_b || lora_r < 1 || lora_ldt < lora_r || lora_ldt > 16 || (lora_seg && (lora_seg & 7)) ||
+                   ((lora_r == 4 && !lora_rmajor) && (lora_ldt & 3)) ||
+                   (lora_t_bf16 && ((lora_ldt != 8 && lora_ldt != 16) || (lora_r != 4 && !lora_rmajor))) ||
+                   (lora_seg && (lora_r != 4 || lora_rmajor || (N / lora_seg) * lora_r > lora_ldt))))
         return mi355_fail(MI355_ERR_ARG, "gemm: bad low-rank operands (r=%d ldt=%d seg=%d)", lora_r, lora_ldt, lora_seg);
     GemmArgs a = {};
     a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
     a.out = out; a.ldo = ldo; a.out_fp32 = out_fp32; a.bias = bias; a.rowbias = rowbias; a.rowbias_div = rowbias_div;
     a.ld_rowbias = ld_rowbias; a.residual = (const bf16_t*)residual; a.ldr = ldr; a.alpha = alpha;
     a.lora_t = lora_t; a.lora_b = lora_b; a.lora_r = lora_r; a.lora_alpha = lora_alpha;
-    a.lora_ldt = lora_ldt; a.lora_seg = lora_seg; a.lora_rmajor = lora_rmajor;
+    a.lora_ldt = lora_ldt; a.lora_seg = lora_seg; a.lora_rmajor = lora_rmajor; a.lora_t_bf16 = lora_t_bf16;
     a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
     return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mi355_gemm_skinny_bf16(const void* A, int lda, const void* Bw, int M, int W, int K, void* out, float alpha, void* stream) {
+    if (!A || !Bw || !out) return mi355_fail(MI355_ERR_ARG, "gemm_skinny: null pointer");
+    if (M < 1 || (W != 8 && W != 16) || K < 32 || (K & 31) || (lda & 7) || lda < K)
+        return mi355_fail(MI355_ERR_ARG, "gemm_skinny: W must be 8 or 16, K a multiple of 32 (M=%d W=%d K=%d lda=%d)", M, W, K, lda);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(FAM_GEMM, s, 2.0 * M * W * K);
+    if (W == 8)
+        hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3((M + 15) / 16), dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bw,
+                           (bf16_t*)out, M, K, alpha);
+    else
+        hipLaunchKernelGGL(gemm_skinny_kernel<16>, dim3((M + 15) / 16), dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bw,
+                           (bf16_t*)out, M, K, alpha);
+    return mi355_check_launch("gemm_skinny");
 }
 
 int mi355_gemm_geglu_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int F, int K, void* out, int ldo,

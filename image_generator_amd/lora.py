@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from ._lib import lib, check
 from . import ops as _ops
-from .ops import BF16, F32, _ptr, _stream, gemm
+from .ops import BF16, F32, _ptr, _stream, gemm, gemm_skinny
 
 
 def _operands(original):
@@ -42,11 +42,12 @@ def _f32c(p):
 class _LoraLinearFn(torch.autograd.Function):
     """y = x W^T + b + alpha * (x A^T) B^T (+ residual).
 
-    `gdst` = (dA_pad [8][K], dB_pad [N][8]) fp32 scratch views: when a weight-gradient queue is installed (a training
-    step of DenoiserTrainer) the adapter gradients dB = alpha dy^T (x A^T) and dA = dt^T x are two more jobs of the
-    grouped MFMA weight-gradient launch, computed from bf16 [M][8] copies of x A^T and dt and written zero-padded to
-    8 ranks; their owner compacts them into the flat gradient buffer once per step.  Without a queue the fp32
-    reduction kernels run and the gradients are returned to autograd."""
+    `gdst` = (dA_pad [8][K], dB_pad [N][8], A16 [8][K], Bt16 [8][N]): the direct-gradient mode of a DenoiserTrainer
+    step.  A16 / Bt16 are per-step bf16 copies of the factors, zero-padded to 8 ranks: t = alpha x A^T and
+    dt = alpha dy B are skinny MFMA GEMMs on them (bf16 [M][8] results that the base GEMMs' epilogues read), and the
+    adapter gradients dB = dy^T t, dA = dt^T x are two more jobs of the grouped MFMA weight-gradient launch, written
+    rank-padded into the fp32 scratch views; the owner compacts them into the flat gradient buffer once per step.
+    Without `gdst` the fp32 side kernels run and the gradients are returned to autograd."""
 
     @staticmethod
     def forward(ctx, x, a, b, bias, alpha, w16, w16_t, residual, gdst):
@@ -58,13 +59,20 @@ class _LoraLinearFn(torch.autograd.Function):
             x2 = x2.to(BF16).contiguous()
         M, r, N = x2.shape[0], a.shape[0], b.shape[0]
         af, bf = _f32c(a), _f32c(b)
-        t = torch.empty((M, r), dtype=F32, device=x.device)
-        queued = gdst is not None and r <= 8 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        t16 = torch.empty((M, 8), dtype=BF16, device=x.device) if queued else None
-        check(lib.mi355_lora_down(x2.data_ptr(), af.data_ptr(), t.data_ptr(), M, K, r, _ptr(t16), alpha, _stream()), "lora_down")
         biasf = None if bias is None else _f32c(bias)
         res2 = None if residual is None else residual.reshape(-1, N)
-        y = gemm(x2, w16, bias=biasf, residual=res2, lora_t=t, lora_b=bf, lora_alpha=alpha)
+        queued = gdst is not None and r <= 8 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        if queued:
+            # training step: t = alpha * x A^T as a skinny MFMA GEMM on the per-step bf16 copy of A (zero-padded to 8
+            # ranks); the same bf16 matrix feeds the epilogue below and the weight-gradient job for dB
+            t = None
+            t16 = gemm_skinny(x2, gdst[2], alpha)
+            y = gemm(x2, w16, bias=biasf, residual=res2, lora_t=t16, lora_b=bf, lora_alpha=1.0)
+        else:
+            t16 = None
+            t = torch.empty((M, r), dtype=F32, device=x.device)
+            check(lib.mi355_lora_down(x2.data_ptr(), af.data_ptr(), t.data_ptr(), M, K, r, None, alpha, _stream()), "lora_down")
+            y = gemm(x2, w16, bias=biasf, residual=res2, lora_t=t, lora_b=bf, lora_alpha=alpha)
         ctx.save_for_backward(x2, t, af, bf, t16)
         ctx.alpha, ctx.w16_t, ctx.xshape, ctx.xdtype, ctx.gdst = alpha, w16_t, x.shape, x.dtype, gdst
         y = y.view(*x.shape[:-1], N)
@@ -79,14 +87,19 @@ class _LoraLinearFn(torch.autograd.Function):
         if dy2.dtype != BF16 or not dy2.is_contiguous():
             dy2 = dy2.to(BF16).contiguous()
         s = _stream()
-        queue = _ops._WGRAD_QUEUE if (ctx.gdst is not None and t16 is not None) else None
-        dt = torch.empty((M, r), dtype=F32, device=dy.device)
-        dt16 = torch.empty((M, 8), dtype=BF16, device=dy.device) if queue is not None else None
-        check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, 1, ctx.alpha, _ptr(dt16), s), "lora_dt")
+        fast = t16 is not None
+        if fast and _ops._WGRAD_QUEUE is None:
+            raise RuntimeError("LoRALinear: direct-gradient mode needs the trainer's weight-gradient queue")
+        queue = _ops._WGRAD_QUEUE if fast else None
+        if fast:
+            dt = dt16 = gemm_skinny(dy2, ctx.gdst[3], ctx.alpha)          # alpha * dy B as a skinny GEMM, bf16 [M][8]
+        else:
+            dt = torch.empty((M, r), dtype=F32, device=dy.device)
+            check(lib.mi355_lora_dt(dy2.data_ptr(), bf.data_ptr(), dt.data_ptr(), M, N, r, 1, ctx.alpha, None, s), "lora_dt")
         da = db = None
         want_a, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         if queue is not None:
-            ga, gb = ctx.gdst
+            ga, gb = ctx.gdst[0], ctx.gdst[1]
             if want_b:          # dB_pad[n][0:8] = sum_m dy[m][n] * (alpha t)[m][0:8]
                 queue.push(dy2, t16, gb, None, M, 1, 1, 8, N, 1, 1, False, 1, 1)
             if want_a:          # dA_pad[0:8][k] = sum_m dt[m][0:8] * x[m][k]
@@ -114,8 +127,9 @@ class LoraFusedFn(torch.autograd.Function):
     its own rank-4 adapter, as ONE GEMM: y[:, s] = x W_s^T + alpha * (x A_s^T) B_s^T.
 
     `lf` carries zero-copy stacked views of the adapters' factors (`A_all` [S*r][K], `B_all` [S*C][r]; the owning
-    model lays the parameters out back to back) and, in direct-gradient mode, the rank-padded scratch views
-    `grad_dst` = (dA_pad [W][K], dB_pad [S*C][W]), W = 8 or 16.  `params` = the 2*S factor parameters
+    model lays the parameters out back to back) and, in direct-gradient mode,
+    `grad_dst` = (dA_pad [W][K], dB_pad [S*C][W], A16 [W][K], Bt16 [W][S*C]), W = 8 or 16: the rank-padded gradient
+    scratch views and the per-step bf16 operands of the skinny GEMMs (Bt16 block-diagonal).  `params` = the 2*S factor parameters
     (A_0, B_0, A_1, B_1, ...) for autograd's bookkeeping."""
 
     @staticmethod
@@ -129,13 +143,18 @@ class LoraFusedFn(torch.autograd.Function):
         M, N, RT = x2.shape[0], pack.n, lf.S * lf.r
         want = any(ctx.needs_input_grad[3:])
         W = 8 if RT <= 8 else 16
-        t = torch.empty((M, RT), dtype=F32, device=x.device)
-        t16 = torch.empty((M, W), dtype=BF16, device=x.device) if want else None
-        check(lib.mi355_lora_down(x2.data_ptr(), lf.A_all.data_ptr(), t.data_ptr(), M, K, RT, _ptr(t16), lf.alpha, _stream()),
-              "lora_down")
-        y = gemm(x2, pack.w16.view(N, K), lora_t=t, lora_b=lf.B_all, lora_alpha=lf.alpha, lora_seg=N // lf.S)
+        fast = want and lf.grad_dst is not None
+        if fast:        # skinny MFMA GEMM on the per-step bf16 copy of the stacked A factors (see _LoraLinearFn)
+            t16 = gemm_skinny(x2, lf.grad_dst[2], lf.alpha)
+            y = gemm(x2, pack.w16.view(N, K), lora_t=t16, lora_b=lf.B_all, lora_alpha=1.0, lora_seg=N // lf.S)
+        else:
+            t = torch.empty((M, RT), dtype=F32, device=x.device)
+            t16 = torch.empty((M, W), dtype=BF16, device=x.device) if want else None
+            check(lib.mi355_lora_down(x2.data_ptr(), lf.A_all.data_ptr(), t.data_ptr(), M, K, RT, _ptr(t16), lf.alpha, _stream()),
+                  "lora_down")
+            y = gemm(x2, pack.w16.view(N, K), lora_t=t, lora_b=lf.B_all, lora_alpha=lf.alpha, lora_seg=N // lf.S)
         ctx.save_for_backward(x2, t16)
-        ctx.pack, ctx.lf, ctx.xshape, ctx.W = pack, lf, x.shape, W
+        ctx.pack, ctx.lf, ctx.xshape, ctx.W, ctx.fast = pack, lf, x.shape, W, fast
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -149,15 +168,20 @@ class LoraFusedFn(torch.autograd.Function):
         if dy2.dtype != BF16 or not dy2.is_contiguous():
             dy2 = dy2.to(BF16).contiguous()
         want = t16 is not None
-        dt = torch.empty((M, S * r), dtype=F32, device=dy.device)
-        dt16 = torch.empty((M, W), dtype=BF16, device=dy.device) if want else None
-        check(lib.mi355_lora_dt(dy2.data_ptr(), lf.B_all.data_ptr(), dt.data_ptr(), M, N, r, S, lf.alpha, _ptr(dt16), _stream()),
-              "lora_dt")
+        if ctx.fast:
+            if _ops._WGRAD_QUEUE is None:
+                raise RuntimeError("LoRA: direct-gradient mode needs the trainer's weight-gradient queue")
+            dt = dt16 = gemm_skinny(dy2, lf.grad_dst[3], lf.alpha)       # block-diagonal B^T operand: dt[:, 4s+q] = alpha dy_s B_s
+        else:
+            dt = torch.empty((M, S * r), dtype=F32, device=dy.device)
+            dt16 = torch.empty((M, W), dtype=BF16, device=dy.device) if want else None
+            check(lib.mi355_lora_dt(dy2.data_ptr(), lf.B_all.data_ptr(), dt.data_ptr(), M, N, r, S, lf.alpha, _ptr(dt16), _stream()),
+                  "lora_dt")
         grads = [None] * (2 * S)
         if want:
-            queue = _ops._WGRAD_QUEUE if lf.grad_dst is not None else None
+            queue = _ops._WGRAD_QUEUE if ctx.fast else None
             if queue is not None:
-                ga, gb = lf.grad_dst
+                ga, gb = lf.grad_dst[0], lf.grad_dst[1]
                 queue.push(dy2, t16, gb, None, M, 1, 1, W, N, 1, 1, False, 1, 1)       # dB_pad = dy^T (alpha t)
                 queue.push(dt16, x2, ga, None, M, 1, 1, K, W, 1, 1, False, 1, 1)       # dA_pad = dt^T x
             else:

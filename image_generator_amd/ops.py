@@ -54,7 +54,8 @@ def _req(t, dtype, name):
 def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=False, alpha=1.0,
          lora_t=None, lora_b=None, lora_alpha=0.0, out=None, lora_seg=0, lora_rmajor=False):
     """out[M,N] = alpha * a[M,K] @ w[N,K]^T (+ bias + rowbias + lora + residual).  a may have a row stride.
-    lora_t [M, r] (or [M, S*r] with lora_seg = N/S for S row-stacked adapters), lora_b [N, r] (or [r, N] if lora_rmajor)."""
+    lora_t fp32 [M, r] (or [M, S*r] with lora_seg = N/S for S row-stacked adapters) or bf16 [M, 8 | 16];
+    lora_b [N, r] (or [r, N] if lora_rmajor)."""
     assert a.dtype == BF16 and w.dtype == BF16 and a.is_cuda
     M, K = a.shape
     N = w.shape[0]
@@ -62,17 +63,31 @@ def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=F
     if out is None:
         out = torch.empty((M, N), dtype=F32 if out_fp32 else BF16, device=a.device)
     ws = workspace(a.device)
-    r = ldt = 0
+    r = ldt = t16 = 0
     if lora_t is not None:
-        assert lora_t.dtype == F32 and lora_b.dtype == F32 and lora_t.is_contiguous() and lora_b.is_contiguous()
+        assert lora_b.dtype == F32 and lora_t.is_contiguous() and lora_b.is_contiguous()
         r = lora_b.shape[0] if lora_rmajor else lora_b.shape[1]
         ldt = lora_t.shape[1]
-        assert lora_t.shape[0] == M and lora_b.numel() == N * r and ldt == (r * (N // lora_seg) if lora_seg else r)
+        t16 = int(lora_t.dtype == BF16)         # bf16 [M, 8 | 16]: zero / don't-care columns beyond the ranks in use
+        assert t16 or lora_t.dtype == F32
+        need = r * (N // lora_seg) if lora_seg else r
+        assert lora_t.shape[0] == M and lora_b.numel() == N * r and (ldt in (8, 16) and ldt >= need if t16 else ldt == need)
     check(lib.mi355_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), K, M, N, K, out.data_ptr(), out.stride(0),
                               1 if out.dtype == F32 else 0, _ptr(bias), _ptr(rowbias), rowbias_div,
                               0 if rowbias is None else rowbias.stride(0), _ptr(residual),
                               0 if residual is None else residual.stride(0), alpha, _ptr(lora_t), ldt, _ptr(lora_b), r,
-                              lora_seg, int(lora_rmajor), lora_alpha, ws.data_ptr(), ws.numel(), _stream()), "gemm")
+                              lora_seg, int(lora_rmajor), t16, lora_alpha, ws.data_ptr(), ws.numel(), _stream()), "gemm")
+    return out
+
+
+def gemm_skinny(a, w, alpha=1.0):
+    """bf16 [M, W] = alpha * a[M, K] @ w[W, K]^T for W in (8, 16): one launch, no split-K workspace."""
+    M, K = a.shape
+    W = w.shape[0]
+    assert a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.is_contiguous() and w.shape[1] == K
+    out = torch.empty((M, W), dtype=BF16, device=a.device)
+    check(lib.mi355_gemm_skinny_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), M, W, K, out.data_ptr(), alpha, _stream()),
+          "gemm_skinny")
     return out
 
 

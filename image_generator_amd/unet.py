@@ -625,7 +625,8 @@ class UNet2DConditionModel(nn.Module):
             n_pad = sum(8 * (m.lora_A.weight.shape[1] + m.lora_B.weight.shape[0]) for m in singles)
             n_pad += sum(width(lf.S * lf.r) * (lf.A_all.shape[1] + lf.B_all.shape[0]) for lf in groups)
             pad = self._grad_pad = torch.zeros(n_pad, dtype=F32, device=g.device)
-            table, q = [], 0
+            op16 = self._lora_op16 = torch.zeros(n_pad, dtype=BF16, device=g.device)    # A16 [W][K] | Bt16 [W][N] per entry
+            table, ptable, q = [], [], 0
             for m in self._adapters:
                 A, Bm = m.lora_A.weight, m.lora_B.weight
                 r, K, N = A.shape[0], A.shape[1], Bm.shape[0]
@@ -636,21 +637,29 @@ class UNet2DConditionModel(nn.Module):
                 A, Bm = m.lora_A.weight, m.lora_B.weight
                 r, K, N = A.shape[0], A.shape[1], Bm.shape[0]
                 ga, gb = pad[q:q + 8 * K].view(8, K), pad[q + 8 * K:q + 8 * (K + N)].view(N, 8)
+                a16, bt16 = op16[q:q + 8 * K].view(8, K), op16[q + 8 * K:q + 8 * (K + N)].view(8, N)
                 q += 8 * (K + N)
-                m.grad_dst = (ga, gb)
+                m.grad_dst = (ga, gb, a16, bt16)
+                ptable.append([0, A.data_ptr(), a16.data_ptr(), r * K, 0, 0])
+                ptable.append([1, Bm.data_ptr(), bt16.data_ptr(), N, r, N])
                 table.append([ga.data_ptr(), A.grad.data_ptr(), r, K, K, K])
                 table.append([gb.data_ptr(), Bm.grad.data_ptr(), N, r, 8, r])
             for lf in groups:
                 S, r, K, N = lf.S, lf.r, lf.A_all.shape[1], lf.B_all.shape[0]
                 W, C = width(S * r), N // S
                 ga, gb = pad[q:q + W * K].view(W, K), pad[q + W * K:q + W * (K + N)].view(N, W)
+                a16, bt16 = op16[q:q + W * K].view(W, K), op16[q + W * K:q + W * (K + N)].view(W, N)
                 q += W * (K + N)
-                lf.grad_dst = (ga, gb)
+                lf.grad_dst = (ga, gb, a16, bt16)
+                ptable.append([0, lf.A_all.data_ptr(), a16.data_ptr(), S * r * K, 0, 0])
+                for i, w in enumerate(lf.mods):      # adapter i: rows i*r .. i*r + r, columns i*C .. i*C + C
+                    ptable.append([1, w.lora_B.weight.data_ptr(), bt16.data_ptr() + 2 * (i * r * N + i * C), C, r, N])
                 # the group's A gradients are adjacent in the flat buffer (same order as the factors themselves)
                 table.append([ga.data_ptr(), lf.mods[0].lora_A.weight.grad.data_ptr(), S * r, K, K, K])
                 for i, w in enumerate(lf.mods):
                     table.append([gb.data_ptr() + 4 * (i * C * W + i * r), w.lora_B.weight.grad.data_ptr(), C, r, W, r])
             self._compact_table = torch.tensor(table, dtype=torch.int64, device=g.device)
+            self._pack_table = torch.tensor(ptable, dtype=torch.int64, device=g.device)
             self._grad_packs = []
             return g
         for p in self.parameters():
@@ -710,6 +719,9 @@ class UNet2DConditionModel(nn.Module):
             return
         if self._frozen_base:       # an adapter that does not run backward this step must end up with a zero gradient
             check(lib.mi355_zero_f32(self._grad_pad.data_ptr(), self._grad_pad.numel(), _stream()), "zero")
+            # this step's bf16 operands of the adapters' skinny GEMMs (the factors changed in the last optimizer step)
+            t = self._pack_table
+            check(lib.mi355_lora_pack(t.data_ptr(), t.shape[0], _stream()), "lora_pack")
             return
         if weights_too:
             check(lib.mi355_zero_f32(self._flat_grad.data_ptr(), self._flat_grad.numel(), _stream()), "zero")

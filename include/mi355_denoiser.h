@@ -48,17 +48,23 @@ int mi355_prof_collect(double* ms, double* work, long long* count);
  * A, Bw, residual bf16; bias, rowbias, lora_t ([M][lora_ldt], first r columns), lora_b fp32; out bf16 or fp32.
  * lora_b is [N][r], or [r][N] when lora_rmajor (the data-gradient GEMM passes lora_A as stored).  lora_seg > 0:
  * the N outputs are row-stacked adapters of lora_seg outputs each and adapter s uses lora_t[m][s*r .. s*r + r).
+ * lora_t_bf16: lora_t is bf16 [M][lora_ldt] with lora_ldt 8 or 16 (the output of a skinny GEMM x.A^T); lora_ldt <= 16.
  * Optional pointers may be NULL.  N, K and all leading dimensions must be multiples of 8. */
 size_t mi355_gemm_workspace_bytes(int M, int N);
 int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
                     int out_fp32, const float* bias, const float* rowbias, int rowbias_div, int ld_rowbias,
                     const void* residual, int ldr, float alpha, const float* lora_t, int lora_ldt, const float* lora_b, int lora_r,
-                    int lora_seg, int lora_rmajor, float lora_alpha, void* workspace, size_t workspace_bytes, void* stream);
+                    int lora_seg, int lora_rmajor, int lora_t_bf16, float lora_alpha, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* 3x3 stride-2 convolution with one pixel of zero padding on the bottom and right only (the AutoencoderKL
  * down-sampler reached through image_generator.py:107-108 `self.vae.encode`): x [B][H][W][C] -> out [B][H/2][W/2][Cout]. */
 int mi355_conv2d_down_asym_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, void* out,
                                 const float* bias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[M][W] (bf16) = alpha * A[M][K] . Bw[W][K]^T for W = 8 or 16 and K a multiple of 32: the rank-padded products
+ * x A^T and dy B of the LoRA adapters (lora.py:23-24) in one launch each, no workspace. */
+int mi355_gemm_skinny_bf16(const void* A, int lda, const void* Bw, int M, int W, int K, void* out, float alpha, void* stream);
 
 /* GEGLU feed-forward input projection with the gate in the epilogue (the transformer block's `ff.net[0]`, reached
  * through image_generator.py:93-95 and :124): Bw [2F][K] = hidden rows then gate rows, bias [2F] or NULL,
@@ -191,6 +197,10 @@ int mi355_lora_dt(const void* dy, const float* Bm, float* dt, int M, int N, int 
  * (A training step computes the same sums on the MFMA weight-gradient queue from the bf16 copies above.) */
 int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, int R, float scale, int flags,
                      void* stream);
+/* bf16 operands of the adapters' skinny GEMMs (t = x A^T, dt = dy B), all adapters in one launch.  n records of 6
+ * int64 in device memory: {0, src, dst, count, 0, 0}: dst[i] = bf16(src[i]);  {1, src fp32 [C][r], dst, C, r, ld}:
+ * dst[q*ld + c] = bf16(src[c*r + q]). */
+int mi355_lora_pack(const long long* table, int n, void* stream);
 /* n records {src, dst, rows, cols, src_ld, dst_ld} (int64, device memory): dst[r][c] = src[r][c], fp32. */
 int mi355_copy2d_f32_batched(const long long* table, int n, void* stream);
 

@@ -160,16 +160,40 @@ def test_lora_in_denoiser_attention_projections():
             for got, want in ((m.lora_A.weight.grad, rm.lora_A.grad), (m.lora_B.weight.grad, rm.lora_B.grad)):
                 a, b = got.float().cpu().flatten(), want.flatten()
                 assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) >= 0.98, n
+    # the direct-gradient mode of the fused trainer (skinny MFMA GEMMs + grouped weight-gradient jobs), same inputs,
+    # against the same oracle gradients
+    from image_generator_amd import ops
+    unet.enable_direct_grads()
+    queue = ops.WgradQueue(torch.device(D))
+    queue.zero_split_outputs = True
+    unet.zero_small_grads(weights_too=False)
+    ops.set_wgrad_queue(queue)
+    try:
+        loss2 = mse_loss(unet(x.to(D), t.to(D), ctx.to(D)).sample, noise.to(D))
+        loss2.backward()
+        queue.join()
+    finally:
+        ops.set_wgrad_queue(None)
+    unet.finish_grads()
+    assert abs(float(loss2.detach()) - float(loss_ref)) <= 1e-2 * float(loss_ref)
+    for n, m in unet.named_modules():
+        if isinstance(m, LoRALinear):
+            rm = ref_mods[n]
+            for got, want in ((m.lora_A.weight.grad, rm.lora_A.grad), (m.lora_B.weight.grad, rm.lora_B.grad)):
+                a, b = got.float().cpu().flatten(), want.flatten()
+                assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) >= 0.98, ("direct", n)
     w = extract_lora_weights(unet)
     assert len(w) == 2 * len(adapters) and all(k.endswith(("lora_A", "lora_B")) for k in w)
     load_lora_weights(unet, w)
 
 
 def test_lora_fused_trainer_step_matches_autograd_path():
-    """Frozen base + adapters on the fused trainer: the adapter gradients that come out of the grouped MFMA
-    weight-gradient launch (bf16 copies of x A^T and dt, rank-padded, compacted into the flat buffer) match the
-    fp32 reduction kernels of the plain autograd path (relative L2 <= 1e-2: bf16 rounding of the rank-4 factors),
-    the optimizer moves the adapters and nothing else, and the graphed step replays the eager one."""
+    """Frozen base + adapters on the fused trainer: x A^T and dy B from skinny MFMA GEMMs on bf16 copies of the
+    factors, adapter gradients from the grouped MFMA weight-gradient launch (rank-padded, compacted into the flat
+    buffer), against the plain autograd path with its fp32 side kernels.  The two forwards differ by bf16 rounding
+    of the low-rank term (loss within 2e-3), which re-rolls the bf16 roundings of every later activation, so the
+    gradients agree like two bf16 runs do: cosine >= 0.995 per parameter, median relative L2 <= 4e-2.  The optimizer
+    moves the adapters and nothing else, and the graphed step replays the eager one."""
     from image_generator_amd.generator import inject_lora
     from image_generator_amd.ops import mse_loss
     from image_generator_amd.trainer import DenoiserTrainer
@@ -197,11 +221,15 @@ def test_lora_fused_trainer_step_matches_autograd_path():
     tr = DenoiserTrainer(unet, lr=1e-3)
     assert tr.opt.frozen_base and tr.opt.flat.numel() == sum(p.numel() for p in unet.parameters() if p.requires_grad)
     loss1 = tr.forward_backward(lat, noise, ts, ctx)
-    assert abs(float(loss1) - float(loss0)) <= 1e-5 * abs(float(loss0))
+    # the trainer path rounds x A^T (and A itself) to bf16 for its skinny MFMA GEMMs, the autograd path keeps them fp32
+    assert abs(float(loss1) - float(loss0)) <= 2e-3 * abs(float(loss0))
+    rels = []
     for n, p in unet.named_parameters():
         if p.requires_grad:
-            rel = float((p.grad - want[n]).norm() / (want[n].norm() + 1e-30))
-            assert rel <= 1e-2, (n, rel)
+            a, b = p.grad.flatten(), want[n].flatten()
+            rels.append(float((a - b).norm() / (b.norm() + 1e-30)))
+            assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) >= 0.995, (n, rels[-1])
+    assert sorted(rels)[len(rels) // 2] <= 4e-2 and max(rels) <= 0.1, (sorted(rels)[len(rels) // 2], max(rels))
     before = tr.opt.flat.clone()
     losses = [float(tr.train_step(lat, noise, ts, ctx)) for _ in range(4)]
     assert not torch.equal(before, tr.opt.flat) and losses[-1] < losses[0]

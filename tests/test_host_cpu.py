@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_rejects_bad_arguments_without_touching_the_gpu():
     from image_generator_amd._lib import lib, check, LibraryError
-    rc = lib.mi355_gemm_bf16(None, 8, None, 8, 8, 8, 8, None, 8, 0, None, None, 1, 0, None, 0, 1.0, None, 0, None, 0, 0, 0, 0.0,
+    rc = lib.mi355_gemm_bf16(None, 8, None, 8, 8, 8, 8, None, 8, 0, None, None, 1, 0, None, 0, 1.0, None, 0, None, 0, 0, 0, 0, 0.0,
                              None, 0, None)
     assert rc == -1 and b"null pointer" in lib.mi355_last_error()
     rc = lib.mi355_conv2d_bf16(1, 1, 4, 4, 8, 1, 8, 5, 1, 0, 0, 4, 4, 1, 0, None, None, 0, None, 1.0, None, 0, None)

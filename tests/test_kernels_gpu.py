@@ -544,3 +544,12 @@ def test_small_utility_entry_points():
     assert abs(outs[0][4] - outs[1][4]) <= 1e-5 * outs[0][4]
     for a, b in zip(outs[0][:4], outs[1][:4]):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,K,W", [(1000, 320, 8), (77 * 5, 768, 8), (4096, 3840, 16), (33, 64, 16)])
+def test_gemm_skinny(M, K, W):
+    from image_generator_amd import ops
+    a, w = rnd(M, K, seed=41), rnd(W, K, scale=K ** -0.5, seed=42)
+    out = ops.gemm_skinny(a.to(dev()), w.to(dev()), 0.5)
+    ref = 0.5 * (a.float() @ w.float().t())
+    close(out, ref, 2 ** -7, 1e-2, f"skinny {M}x{W}x{K}")
