@@ -64,10 +64,22 @@ __device__ __forceinline__ float gemm_gelu_erf(float x) { return gelu_erf_f(x); 
 // Shared tail of both GEMM kernels: split-K slab store, or the LDS-staged vectorised epilogue.
 // Low-rank term of 8 adjacent outputs: v[e] += lora_alpha * sum_r t[m][r] * b(n + e, r).  `lora_seg` > 0: the columns
 // are row-stacked adapters of `lora_seg` outputs each and adapter s reads t[m][s*r .. s*r + r) (fused projections).
-__device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, float (&v)[8]) {
-    const int toff = p.lora_seg ? (n / p.lora_seg) * p.lora_r : 0;
+// `fb` / `fld`: where the factors of column n are read from - global memory (fb = lora_b + n * r resp. lora_b + n,
+// fld = N) or the per-tile copy the epilogue staged in LDS (fld = tile width).  `trow`: the row's 16 fp32 low-rank
+// activations staged in LDS, or null to read them from global memory.
+__device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, float (&v)[8], const float* fb, int fld,
+                                           const float* trow) {
+    // adapter index of column n (at most 4 row-stacked adapters) without an integer division
+    const int toff = p.lora_seg ? ((n >= p.lora_seg) + (n >= 2 * p.lora_seg) + (n >= 3 * p.lora_seg)) * p.lora_r : 0;
     float tv[16];
-    if (p.lora_t_bf16) {                        // bf16 [M][ldt] (ldt = 8 or 16), e.g. the output of a skinny GEMM
+    if (trow) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t4 = *(const f32x4*)(trow + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tv[4 * q + r] = t4[r];
+        }
+    } else if (p.lora_t_bf16) {                 // bf16 [M][ldt] (ldt = 8 or 16), e.g. the output of a skinny GEMM
         const bf16_t* t = (const bf16_t*)p.lora_t + (size_t)m * p.lora_ldt;
         const bf16x8 lo = *(const bf16x8*)t;
         const bf16x8 hi = p.lora_ldt > 8 ? *(const bf16x8*)(t + 8) : lo;
@@ -78,12 +90,22 @@ __device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) tv[r] = r < p.lora_ldt ? t[r] : 0.f;
     }
-    if (p.lora_rmajor) {                        // factors [r][N]: eight adjacent columns are two 16-byte loads per rank
+    if (trow && !p.lora_rmajor) {               // LDS copy of [N][4] factors, staged as [4][tile width]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = toff == 0 ? tv[r] : toff == 4 ? tv[4 + r] : toff == 8 ? tv[8 + r] : tv[12 + r];
+            const float tr = a * p.lora_alpha;
+            const float* bp = fb + r * fld;
+            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += tr * b0[e]; v[4 + e] += tr * b1[e]; }
+        }
+    } else if (p.lora_rmajor) {                 // factors [r][N]: eight adjacent columns are two 16-byte loads per rank
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (r < p.lora_r) {
                 const float tr = tv[r] * p.lora_alpha;
-                const float* bp = p.lora_b + (size_t)r * p.N + n;
+                const float* bp = fb + (size_t)r * fld;
                 const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += tr * b0[e]; v[4 + e] += tr * b1[e]; }
@@ -97,7 +119,7 @@ __device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, floa
             const float a = toff == 0 ? tv[r] : toff == 4 ? tv[4 + r] : toff == 8 ? tv[8 + r] : tv[12 + r];
             t4[r] = a * p.lora_alpha;
         }
-        const f32x4* bp = (const f32x4*)(p.lora_b + (size_t)n * 4);
+        const f32x4* bp = (const f32x4*)fb;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const f32x4 bv = bp[e];
@@ -135,8 +157,46 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 
     // ---- epilogue through LDS, 64 rows at a time
     float* ep = (float*)smem;
+    // Low-rank factors of this tile's BN columns, staged once behind the staging rows: read from global memory per
+    // 8-column chunk they cost 128 B of L1 traffic per 16 B of output (measured +87 us on a 38 us GEMM).
+    float* lf = ep + 64 * EP_LD;
+    float* lt = lf + 16 * BN;                  // [64][16] low-rank activations of the current 64 rows (fp32)
+    const bool lora_lds = p.lora_t && (p.lora_rmajor || p.lora_r == 4);
+    if (lora_lds) {
+        if (p.lora_rmajor) {
+            for (int i = tid; i < p.lora_r * BN; i += NTHREADS) {
+                const int r = i / BN, c = i - r * BN;
+                lf[i] = n0 + c < p.N ? p.lora_b[(size_t)r * p.N + n0 + c] : 0.f;
+            }
+        } else {
+            // [N][4] factors are staged transposed ([4][BN], like the [r][N] form): read per column they would sit
+            // 128 B apart, two bank groups for a whole wave
+            for (int i = tid; i < BN * 4; i += NTHREADS)
+                lf[(i & 3) * BN + (i >> 2)] = n0 + (i >> 2) < p.N ? p.lora_b[(size_t)n0 * 4 + i] : 0.f;
+        }
+    }
+    // low-rank activations of all BM rows, four per thread and 64-row group (zero past lora_ldt), fetched up front so
+    // that their global-memory latency is paid once and not inside every group's barrier interval
+    f32x4 tpre[BM / 64];
+    if (lora_lds && tid < 256) {
+#pragma unroll
+        for (int h = 0; h < BM / 64; ++h) {
+            const int q4 = (tid & 3) * 4, m = m0 + h * 64 + (tid >> 2);
+            f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+            if (m < p.M && q4 < p.lora_ldt) {
+                if (p.lora_t_bf16) {
+                    const bf16x4 tb = *(const bf16x4*)((const bf16_t*)p.lora_t + (size_t)m * p.lora_ldt + q4);
+                    t4 = f32x4{(float)tb[0], (float)tb[1], (float)tb[2], (float)tb[3]};
+                } else {
+                    t4 = *(const f32x4*)(p.lora_t + (size_t)m * p.lora_ldt + q4);
+                }
+            }
+            tpre[h] = t4;
+        }
+    }
     for (int h = 0; h < BM / 64; ++h) {
         __syncthreads();
+        if (lora_lds && tid < 256) *(f32x4*)(lt + (tid >> 2) * 16 + (tid & 3) * 4) = tpre[h];
         // the wave stages those of its 16-row blocks that lie inside this 64-row group
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -208,7 +268,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
             }
-            if (p.lora_t) lora_apply(p, m, n, v);
+            if (p.lora_t) {
+                if (lora_lds) lora_apply(p, m, n, v, lf + c8 * 8, BN, lt + row * 16);
+                else lora_apply(p, m, n, v, p.lora_b + (size_t)n * p.lora_r, p.N, nullptr);
+            }
             if (p.residual) {
                 const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
@@ -763,7 +826,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
         }
-        if (p.lora_t) lora_apply(p, m, n, v);
+        if (p.lora_t) lora_apply(p, m, n, v, p.lora_rmajor ? p.lora_b + n : p.lora_b + (size_t)n * p.lora_r, p.N, nullptr);
         if (p.residual) {
             const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
@@ -797,7 +860,9 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
 
 template <int AMODE>
 static int launch_gemm_wide(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
-    constexpr int smem = 2 * 26 * 1024;
+    // two 26 KiB stages; the epilogue re-uses them for 64 staging rows + low-rank factors + low-rank activations
+    constexpr int smem = (64 * 164 + 16 * 160 + 64 * 16) * 4;
+    static_assert(smem >= 2 * 26 * 1024, "stages must fit");
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_wide_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
