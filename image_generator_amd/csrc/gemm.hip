@@ -37,6 +37,7 @@ struct GemmArgs {
     const float* bias;       // [N] or null
     const float* rowbias;    // [M / rowbias_div][ld_rowbias] or null
     int rowbias_div, ld_rowbias;
+    int rowbias_shift;       // log2(rowbias_div) when it is a power of two (no integer division per chunk), else -1
     const bf16_t* residual;  // [M][ldr] or null
     int ldr;
     float alpha;
@@ -57,7 +58,10 @@ struct GemmArgs {
     ConvGeom g;
 };
 
-enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2 };
+// AMODE_DENSE_LORA: dense A with the low-rank term in the epilogue - a kernel variant of its own so that every other
+// GEMM keeps the short epilogue (carrying the low-rank code path cost them 0.3 ms per training step)
+enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2, AMODE_DENSE_LORA = 3 };
+__host__ __device__ constexpr bool amode_dense(int amode) { return amode == AMODE_DENSE || amode == AMODE_DENSE_LORA; }
 
 __device__ __forceinline__ float gemm_gelu_erf(float x) { return gelu_erf_f(x); }
 
@@ -135,7 +139,7 @@ __device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, floa
     }
 }
 
-template <int BN, int TM, int TN, int NTHREADS = 256, int BM = 128>
+template <int BN, int TM, int TN, int NTHREADS = 256, int BM = 128, bool LORA = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], char* smem, int m0, int n0,
                                               int split, int wm0, int wn0, int wave, int tid, int fr, int fq) {
     constexpr int EP_LD = BN + 4;
@@ -161,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     // 8-column chunk they cost 128 B of L1 traffic per 16 B of output (measured +87 us on a 38 us GEMM).
     float* lf = ep + 64 * EP_LD;
     float* lt = lf + 16 * BN;                  // [64][16] low-rank activations of the current 64 rows (fp32)
-    const bool lora_lds = p.lora_t && (p.lora_rmajor || p.lora_r == 4);
+    const bool lora_lds = LORA && p.lora_t && (p.lora_rmajor || p.lora_r == 4);
     if (lora_lds) {
         if (p.lora_rmajor) {
             for (int i = tid; i < p.lora_r * BN; i += NTHREADS) {
@@ -263,12 +267,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
             }
             if (p.rowbias) {
-                const float* rb = p.rowbias + (size_t)(m / p.rowbias_div) * p.ld_rowbias + n;
+                const float* rb = p.rowbias + (size_t)(p.rowbias_shift >= 0 ? m >> p.rowbias_shift : m / p.rowbias_div) * p.ld_rowbias + n;
                 const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
             }
-            if (p.lora_t) {
+            if (LORA && p.lora_t) {
                 if (lora_lds) lora_apply(p, m, n, v, lf + c8 * 8, BN, lt + row * 16);
                 else lora_apply(p, m, n, v, p.lora_b + (size_t)n * p.lora_r, p.N, nullptr);
             }
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const int m = m0 + r0 + 32 * i;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
-        if constexpr (AMODE == AMODE_DENSE) {
+        if constexpr (amode_dense(AMODE)) {
             a_base[i] = p.A + (size_t)mm * p.lda;
             a_iy0[i] = a_ix0[i] = 0;
         } else {
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     auto load_tile = [&](int kt) {
         const int k = kt * BK + cc * 8;
         const bool k_ok = k < p.K;
-        if constexpr (AMODE == AMODE_DENSE) {
+        if constexpr (amode_dense(AMODE)) {
 #pragma unroll
             for (int i = 0; i < A_CH; ++i)
                 a_reg[i] = (a_ok[i] && k_ok) ? *(const bf16x8*)(a_base[i] + k) : zero8;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         cur ^= 1;
     }
 
-    gemm_epilogue<BN, TM, TN>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+    gemm_epilogue<BN, TM, TN, 256, 128, AMODE == AMODE_DENSE_LORA>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     for (int j = 0; j < A_P; ++j) {
         const int m = m0 + (wave + NW * j) * 8 + sr;
         const bool ok = m < p.M;
-        if constexpr (AMODE == AMODE_DENSE) {
+        if constexpr (amode_dense(AMODE)) {
             a_voff[j] = ok ? (m * p.lda + kc * 8) * 2 : OOB_OFF;
             a_iy0[j] = a_ix0[j] = 0;
         } else {
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     auto issue = [&](int kt, int stage) {
         char* As = smem + stage * STAGE;
         char* Bs = As + BM * 128;
-        if constexpr (AMODE == AMODE_DENSE) {
+        if constexpr (amode_dense(AMODE)) {
             const int soff = kt * (BK * 2);
 #pragma unroll
             for (int j = 0; j < A_P; ++j)
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BN, TM, TN, NW * 64, BM>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+    gemm_epilogue<BN, TM, TN, NW * 64, BM, AMODE == AMODE_DENSE_LORA>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
 #endif
 }
 
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
         if (pc < A_PIECES) {
             const int m = m0 + pc * 16 + prow;
             const bool ok = m < p.M;
-            if constexpr (AMODE == AMODE_DENSE) {
+            if constexpr (amode_dense(AMODE)) {
                 voff[q] = ok ? (m * p.lda + kc * 8) * 2 : OOB_OFF;
             } else {
                 const int mm = ok ? m : 0;
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
         char* base = smem + stage * STAGE;
         const int soffb = kt * (BK * 2);
         int soffa = soffb, ky = 0, kx = 0;
-        if constexpr (AMODE != AMODE_DENSE) {
+        if constexpr (!amode_dense(AMODE)) {
             const int kk = kt * BK;
             const int tap = kk / p.g.C;
             soffa = (kk - tap * p.g.C) * 2;
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
             if (pc >= PIECES) continue;
             if (pc < A_PIECES) {
                 int v = voff[q];
-                if constexpr (AMODE != AMODE_DENSE) {
+                if constexpr (!amode_dense(AMODE)) {
                     int sy = iy0[q] + ky, sx = ix0[q] + kx;
                     bool ok = voff[q] >= 0 && sy >= 0 && sx >= 0;
                     if (p.g.dil) {
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BN, TM, TN, 256, BM>(p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq);
+    gemm_epilogue<BN, TM, TN, 256, BM, AMODE == AMODE_DENSE_LORA>(p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq);
 #endif
 }
 
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
         }
         if (p.rowbias) {
-            const float* rb = p.rowbias + (size_t)(m / p.rowbias_div) * p.ld_rowbias + n;
+            const float* rb = p.rowbias + (size_t)(p.rowbias_shift >= 0 ? m >> p.rowbias_shift : m / p.rowbias_div) * p.ld_rowbias + n;
             const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
@@ -920,12 +924,17 @@ static int pick_splitk(int tiles, int nkt, double out_elems, int bn) {
 static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return mi355_fail(MI355_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     if ((a.N & 7) || (a.K & 7)) return mi355_fail(MI355_ERR_ARG, "gemm: N (%d) and K (%d) must be multiples of 8", a.N, a.K);
-    if ((a.ldb & 7) || (a.ldo & 7) || (amode == AMODE_DENSE && (a.lda & 7)))
+    if ((a.ldb & 7) || (a.ldo & 7) || (amode_dense(amode) && (a.lda & 7)))
         return mi355_fail(MI355_ERR_ARG, "gemm: leading dimensions must be multiples of 8 elements");
     if (a.residual && (a.ldr & 7)) return mi355_fail(MI355_ERR_ARG, "gemm: residual stride must be a multiple of 8");
     if (a.rowbias && a.rowbias_div <= 0) return mi355_fail(MI355_ERR_ARG, "gemm: rowbias_div must be positive");
     if (((uintptr_t)a.bias & 15) || ((uintptr_t)a.rowbias & 15) || (a.rowbias && (a.ld_rowbias & 3)))
         return mi355_fail(MI355_ERR_ARG, "gemm: bias / rowbias must be 16-byte aligned (rowbias stride a multiple of 4 floats)");
+    a.rowbias_shift = -1;
+    if (a.rowbias_div > 0 && !(a.rowbias_div & (a.rowbias_div - 1))) {
+        a.rowbias_shift = 0;
+        while ((1 << a.rowbias_shift) < a.rowbias_div) ++a.rowbias_shift;
+    }
     int bn;
     if (a.N % 160 == 0) bn = 160;
     else if (a.N <= 64) bn = 64;
@@ -947,11 +956,11 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     int rc;
     // LDS-DMA kernel when the shape allows it (every large layer of the denoiser does)
     static const bool force_v1 = getenv("MI355_GEMM_V1") != nullptr;
-    const double a_sz = amode == AMODE_DENSE ? ((double)(a.M - 1) * a.lda + a.K) * 2.0
+    const double a_sz = amode_dense(amode) ? ((double)(a.M - 1) * a.lda + a.K) * 2.0
                                              : (double)a.g.B * a.g.H * a.g.W * a.g.C * 2.0;
     const double b_sz = ((double)(a.N - 1) * a.ldb + a.K) * 2.0;
     const bool dma_ok = !force_v1 && a.K % 64 == 0 && amode != AMODE_CONV_GENERIC && a_sz < 2.0e9 && b_sz < 2.0e9 &&
-                        (double)a.M * (amode == AMODE_DENSE ? a.lda : 1) < 1.0e9;
+                        (double)a.M * (amode_dense(amode) ? a.lda : 1) < 1.0e9;
     if (a.geglu && !dma_ok) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_geglu: needs K %% 64 == 0 and operands < 2 GB");
     a.bm = 128;
     {   // 256-row tiles when the grid still gives every CU its two workgroups
@@ -965,10 +974,13 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     }
     if (dma_ok && a.bm == 256) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
-        rc = amode == AMODE_DENSE ? launch_gemm_wide<AMODE_DENSE>(a, ab, bb, s) : launch_gemm_wide<AMODE_CONV_FAST>(a, ab, bb, s);
+        rc = amode == AMODE_DENSE ? launch_gemm_wide<AMODE_DENSE>(a, ab, bb, s)
+             : amode == AMODE_DENSE_LORA ? launch_gemm_wide<AMODE_DENSE_LORA>(a, ab, bb, s)
+                                         : launch_gemm_wide<AMODE_CONV_FAST>(a, ab, bb, s);
     } else if (dma_ok) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
 #define DISPATCH_DMA(BN) (amode == AMODE_DENSE ? launch_gemm_dma<BN, AMODE_DENSE>(a, ab, bb, s) \
+                          : amode == AMODE_DENSE_LORA ? launch_gemm_dma<BN, AMODE_DENSE_LORA>(a, ab, bb, s) \
                                                : launch_gemm_dma<BN, AMODE_CONV_FAST>(a, ab, bb, s))
         if (bn == 160) rc = DISPATCH_DMA(160);
         else if (bn == 64) rc = DISPATCH_DMA(64);
@@ -977,6 +989,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     } else {
 #define DISPATCH(BN)                                                                       \
     (amode == AMODE_DENSE ? launch_gemm<BN, AMODE_DENSE>(a, s)                             \
+     : amode == AMODE_DENSE_LORA ? launch_gemm<BN, AMODE_DENSE_LORA>(a, s)                 \
      : amode == AMODE_CONV_FAST ? launch_gemm<BN, AMODE_CONV_FAST>(a, s)                   \
                                 : launch_gemm<BN, AMODE_CONV_GENERIC>(a, s))
     if (bn == 160) rc = DISPATCH(160);
@@ -1022,7 +1035,7 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
     a.lora_t = lora_t; a.lora_b = lora_b; a.lora_r = lora_r; a.lora_alpha = lora_alpha;
     a.lora_ldt = lora_ldt; a.lora_seg = lora_seg; a.lora_rmajor = lora_rmajor; a.lora_t_bf16 = lora_t_bf16;
     a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
-    return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
+    return run_gemm(a, lora_t ? AMODE_DENSE_LORA : AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int mi355_gemm_skinny_bf16(const void* A, int lda, const void* Bw, int M, int W, int K, void* out, float alpha, void* stream) {
