@@ -137,6 +137,40 @@ static __global__ void reduce_rows_kernel(const float* __restrict__ partial, flo
     }
 }
 
+// Many row reductions in one launch: record e = {partial, out, out_hi, R, N, split} (int64), blockIdx.y picks the
+// record, blockIdx.x the 64-column slab (slabs past N exit).  Same arithmetic as reduce_rows_kernel.
+static __global__ void reduce_rows_batched_kernel(const long long* __restrict__ table) {
+    const long long* e = table + 6 * blockIdx.y;
+    const float* partial = (const float*)e[0];
+    float* out = (float*)e[1];
+    float* out_hi = (float*)e[2];
+    const int R = (int)e[3], N = (int)e[4], split = (int)e[5];
+    if ((int)blockIdx.x * 64 >= N) return;
+    __shared__ f32x4 red[16][16];
+    const int cg = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + cg * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        const float* src = partial + col;
+        int r = ph;
+        for (; r + 48 < R; r += 64) {
+            const f32x4 a = *(const f32x4*)(src + (size_t)r * N), b = *(const f32x4*)(src + (size_t)(r + 16) * N);
+            const f32x4 c = *(const f32x4*)(src + (size_t)(r + 32) * N), d = *(const f32x4*)(src + (size_t)(r + 48) * N);
+            acc += (a + b) + (c + d);
+        }
+        for (; r < R; r += 16) acc += *(const f32x4*)(src + (size_t)r * N);
+    }
+    red[ph][cg] = acc;
+    __syncthreads();
+    if (ph == 0 && col < N) {
+        f32x4 t = red[0][cg];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += red[q][cg];
+        if (out_hi != nullptr && col >= split) *(f32x4*)(out_hi + col - split) = t;
+        else *(f32x4*)(out + col) = t;
+    }
+}
+
 // Blocks that share an XCD (ids congruent mod 8) get one contiguous chunk of the logical grid.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;

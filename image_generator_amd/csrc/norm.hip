@@ -502,4 +502,13 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
     return mi355_check_launch("layernorm_bwd");
 }
 
+// Deferred parameter-gradient reductions of many norm layers in one launch.  table: n records of 6 int64 in device
+// memory {partial rows, out, out_hi (or 0), rows, N, split}: out[c] = sum_r partial[r][c] for c < split (or all c when
+// out_hi is 0), out_hi[c - split] otherwise.  max_cols: the largest N.  N and split multiples of 4.
+int mi355_reduce_rows_batched(const long long* table, int n, int max_cols, void* stream) {
+    if (!table || n < 1 || max_cols < 4) return mi355_fail(MI355_ERR_ARG, "reduce_rows_batched: bad arguments");
+    hipLaunchKernelGGL(reduce_rows_batched_kernel, dim3((max_cols + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, table);
+    return mi355_check_launch("reduce_rows_batched");
+}
+
 }  // extern "C"

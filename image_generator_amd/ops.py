@@ -244,6 +244,56 @@ def set_wgrad_queue(q):
     _WGRAD_QUEUE = q
 
 
+class ReduceQueue:
+    """Deferred parameter-gradient reductions of the norm layers: in direct-gradient mode their backward kernels
+    leave per-workgroup partial rows in scratch and push one record here; `flush()` reduces all of them (109 layers
+    of the denoiser) with ONE launch into the flat gradient buffer instead of one small launch per layer."""
+
+    def __init__(self, device, max_entries=256, ring=8):
+        self.device = device
+        self.max_entries = max_entries
+        self._ring = [torch.empty(max_entries * 6, dtype=torch.int64).pin_memory() for _ in range(ring)]
+        self._ring_size, self._ri = ring, 0
+        self._keep = []          # pinned tables referenced by captured graphs
+        self._entries, self._refs, self._max_cols = [], [], 0
+
+    def push(self, partial_ptr, out, out_hi, rows, n, split, scratch):
+        self._entries.append((partial_ptr, out.data_ptr(), 0 if out_hi is None else out_hi.data_ptr(), rows, n, split))
+        self._refs.append(scratch)          # the partial rows must outlive the flush
+        self._max_cols = max(self._max_cols, n)
+        if len(self._entries) == self.max_entries:
+            self.flush()
+
+    def flush(self):
+        n = len(self._entries)
+        if n == 0:
+            return
+        host = self._ring[self._ri]
+        host[:6 * n] = torch.tensor(self._entries, dtype=torch.int64).view(-1)
+        table = torch.empty(6 * n, dtype=torch.int64, device=self.device)
+        table.copy_(host[:6 * n], non_blocking=True)
+        check(lib.mi355_reduce_rows_batched(table.data_ptr(), n, self._max_cols, _stream()), "reduce_rows_batched")
+        if torch.cuda.is_current_stream_capturing():
+            self._keep.append(self._ring.pop(self._ri))     # the graph re-reads this table on every replay
+            if not self._ring:
+                raise RuntimeError("ReduceQueue: pinned table ring exhausted during graph capture")
+            self._ri %= len(self._ring)
+        else:
+            while len(self._ring) < self._ring_size:
+                self._ring.append(torch.empty(self.max_entries * 6, dtype=torch.int64).pin_memory())
+            self._ri = (self._ri + 1) % len(self._ring)
+        self._keep_last = (table, self._refs)       # alive until the next flush (the launch is asynchronous)
+        self._entries, self._refs, self._max_cols = [], [], 0
+
+
+_REDUCE_QUEUE = None
+
+
+def set_reduce_queue(q):
+    global _REDUCE_QUEUE
+    _REDUCE_QUEUE = q
+
+
 def colsum(y2d, seg=None):
     M, N = y2d.shape
     seg = M if seg is None else seg
@@ -552,10 +602,15 @@ class GroupNormFn(torch.autograd.Function):
         direct = ctx.gdst is not None
         frozen = not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])      # affine parameters without gradient
         dg, db = ctx.gdst if direct else ((None, None) if frozen else (torch.empty_like(gamma), torch.empty_like(beta)))
-        scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, G)), dtype=F32, device=x.device)
+        nsc = int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, G))
+        scratch = torch.empty(nsc, dtype=F32, device=x.device)
+        deferred = direct and not frozen and _REDUCE_QUEUE is not None
         check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                      dx.data_ptr(), _ptr(dg), _ptr(db), scratch.data_ptr(), B, H * W, C, G,
-                                      int(ctx.silu), _ptr(dpass), _stream()), "groupnorm_bwd")
+                                      dx.data_ptr(), None if deferred else _ptr(dg), None if deferred else _ptr(db),
+                                      scratch.data_ptr(), B, H * W, C, G, int(ctx.silu), _ptr(dpass), _stream()), "groupnorm_bwd")
+        if deferred:        # per-strip channel partials follow the group partials in scratch
+            strips = nsc // (B * (2 * G + 2 * C))
+            _REDUCE_QUEUE.push(scratch.data_ptr() + 4 * B * strips * G * 2, db, dg, B * strips, 2 * C, C, scratch)
         if direct or frozen:
             return dx, None, None, None, None, None, None, None
         return dx, dg, db, None, None, None, None, None
@@ -590,9 +645,14 @@ class LayerNormFn(torch.autograd.Function):
         direct = ctx.gdst is not None
         frozen = not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         dgb = ctx.gdst if direct else (None if frozen else torch.empty((2, C), dtype=F32, device=x.device))
-        scratch = torch.empty(int(lib.mi355_layernorm_bwd_scratch_floats(M, C)), dtype=F32, device=x.device)
+        nsc = int(lib.mi355_layernorm_bwd_scratch_floats(M, C))
+        scratch = torch.empty(nsc, dtype=F32, device=x.device)
+        deferred = direct and not frozen and _REDUCE_QUEUE is not None
         check(lib.mi355_layernorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                                      _ptr(dgb), scratch.data_ptr(), M, C, _ptr(dpass), _stream()), "layernorm_bwd")
+                                      None if deferred else _ptr(dgb), scratch.data_ptr(), M, C, _ptr(dpass), _stream()),
+              "layernorm_bwd")
+        if deferred:
+            _REDUCE_QUEUE.push(scratch.data_ptr(), dgb, None, nsc // (2 * C), 2 * C, 0, scratch)
         if direct or frozen:
             return dx, None, None, None, None, None
         return dx, dgb[0], dgb[1], None, None, None

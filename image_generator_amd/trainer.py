@@ -262,6 +262,8 @@ class DenoiserTrainer:
         self.wgrad_queue = _ops.WgradQueue(dev, side_stream=side) if os.environ.get("MI355_NO_WGRAD_QUEUE") != "1" else None
         if self.wgrad_queue is not None:
             self.wgrad_queue.zero_split_outputs = True
+        # norm-layer parameter gradients: one batched reduction per step instead of one launch per layer
+        self.reduce_queue = _ops.ReduceQueue(dev) if os.environ.get("MI355_NO_REDUCE_QUEUE") != "1" else None
 
     def forward_backward(self, latents, noise, t, ctx):
         B = latents.shape[0]
@@ -273,12 +275,16 @@ class DenoiserTrainer:
         pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
         loss = mse_loss(pred, noise)
         self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched
+        self._ops.set_reduce_queue(self.reduce_queue)
         try:
             loss.backward()
             if self.wgrad_queue is not None:
                 self.wgrad_queue.join()
+            if self.reduce_queue is not None:
+                self.reduce_queue.flush()
         finally:
             self._ops.set_wgrad_queue(None)
+            self._ops.set_reduce_queue(None)
         self.unet.finish_grads()
         if self.reducer is not None:
             self.reducer.finish()

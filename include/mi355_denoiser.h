@@ -128,6 +128,12 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
                         const void* dres, void* stream);
+/* The reductions that the two backward calls skip when given NULL parameter-gradient pointers, for many layers in
+ * one launch: n records of 6 int64 in device memory {partial, out, out_hi | 0, rows, N, split}; out[c] = sum over
+ * rows of partial[r][c] for c < split (every c when out_hi is 0), out_hi[c - split] otherwise.  GroupNorm: partial =
+ * scratch + B*strips*G*2 floats with strips = scratch_floats / (B*(2G + 2C)), rows = B*strips, N = 2C, out = dbeta,
+ * out_hi = dgamma, split = C.  LayerNorm: partial = scratch, rows = scratch_floats / 2C, N = 2C, out = dgamma_dbeta. */
+int mi355_reduce_rows_batched(const long long* table, int n, int max_cols, void* stream);
 /* LayerNorm over rows of [M][C]; stats [M][2] = (mean, rstd). */
 int mi355_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C,
                         float eps, void* stream);
