@@ -240,6 +240,144 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small maps (8x8 and 4x4 levels, group width a multiple of 8 channels): one workgroup per (group, sample) holds its
+// whole slab - at most 768 chunks of 8 channels - in registers, so the forward is ONE kernel that reads x once and
+// the backward ONE kernel that reads x and dy once.  The strip kernels above need two launches each way and are
+// latency-bound on these 1-5 MB maps (7 + 6 us forward, 12 + 9 us backward against ~5 and ~7 us here).
+// ---------------------------------------------------------------------------------------------
+constexpr int GNS_MAXCH = 3;        // backward: slab <= 768 chunks (registers: dz, xhat, gamma per element)
+constexpr int GNS_MAXCH_FWD = 5;    // forward only keeps x: slabs up to 1280 chunks (1280 channels at 16x16)
+static bool gn_small(int HW, int C, int G) {
+    const int cg = C / G;
+    return C % G == 0 && cg % 8 == 0 && HW <= 64 && HW * (cg / 8) <= 256 * GNS_MAXCH;
+}
+static bool gn_small_fwd(int HW, int C, int G) {
+    const int cg = C / G;
+    return C % G == 0 && cg % 8 == 0 && HW <= 256 && HW * (cg / 8) <= 256 * GNS_MAXCH_FWD;
+}
+
+__global__ __launch_bounds__(256) void gn_small_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                           float* __restrict__ stats, int HW, int C, int G, int silu, float eps) {
+    __shared__ float red[2][16];
+    const int g = blockIdx.x, b = blockIdx.y, cg = C / G, ncc = cg >> 3, n = HW * ncc;
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg;
+    float v[GNS_MAXCH_FWD][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < GNS_MAXCH_FWD; ++k) {
+        const int idx = threadIdx.x + 256 * k;
+        if (idx < n) {
+            const int row = idx / ncc, cc = idx - row * ncc;
+            const bf16x8 t = *(const bf16x8*)(x + base + (size_t)row * C + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[k][e] = (float)t[e]; s += v[k][e]; }
+        }
+    }
+    const float inv_n = 1.f / (float)(HW * cg);
+    const float mean = block_sum(s, red[0]) * inv_n;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < GNS_MAXCH_FWD; ++k) {
+        if (threadIdx.x + 256 * k < n) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(block_sum(ss, red[1]) * inv_n + eps);
+    if (threadIdx.x == 0) {
+        stats[((size_t)b * G + g) * 2] = mean;
+        stats[((size_t)b * G + g) * 2 + 1] = rstd;
+    }
+#pragma unroll
+    for (int k = 0; k < GNS_MAXCH_FWD; ++k) {
+        const int idx = threadIdx.x + 256 * k;
+        if (idx < n) {
+            const int row = idx / ncc, cc = idx - row * ncc;
+            const float* ga = gamma + g * cg + cc * 8;
+            const float* be = beta + g * cg + cc * 8;
+            const f32x4 g0 = *(const f32x4*)ga, g1 = *(const f32x4*)(ga + 4), b0 = *(const f32x4*)be, b1 = *(const f32x4*)(be + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float z = (v[k][e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+                if (silu) z = silu_f(z);
+                o[e] = (bf16_t)z;
+            }
+            *(bf16x8*)(y + base + (size_t)row * C + cc * 8) = o;
+        }
+    }
+}
+
+// cpart (optional): [B][2][C] per-sample channel sums (first plane sum dz, second sum dz * xhat) for dbeta / dgamma.
+__global__ __launch_bounds__(256) void gn_small_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_t* __restrict__ dx,
+                                                           float* __restrict__ cpart, const bf16_t* __restrict__ dres,
+                                                           int HW, int C, int G, int silu) {
+    extern __shared__ float pc[];            // [chunk][16]: 8 x dz, 8 x dz*xhat per chunk (parameter gradients only)
+    __shared__ float red[2][16];
+    const int g = blockIdx.x, b = blockIdx.y, cg = C / G, ncc = cg >> 3, n = HW * ncc;
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg;
+    const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
+    float dz[GNS_MAXCH][8], xh[GNS_MAXCH][8], gw[GNS_MAXCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < GNS_MAXCH; ++k) {
+        const int idx = threadIdx.x + 256 * k;
+        if (idx < n) {
+            const int row = idx / ncc, cc = idx - row * ncc;
+            const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)row * C + cc * 8);
+            const bf16x8 dv = *(const bf16x8*)(dy + base + (size_t)row * C + cc * 8);
+            const float* ga = gamma + g * cg + cc * 8;
+            const float* be = beta + g * cg + cc * 8;
+            const f32x4 g0 = *(const f32x4*)ga, g1 = *(const f32x4*)(ga + 4), b0 = *(const f32x4*)be, b1 = *(const f32x4*)(be + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gam = e < 4 ? g0[e] : g1[e - 4];
+                const float h = ((float)xv[e] - mean) * rstd;
+                float d = (float)dv[e];
+                if (silu) d *= silu_grad_f(h * gam + (e < 4 ? b0[e] : b1[e - 4]));
+                dz[k][e] = d; xh[k][e] = h; gw[k][e] = gam;
+                s1 += gam * d;
+                s2 += gam * d * h;
+            }
+            if (cpart) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { pc[idx * 16 + e] = dz[k][e]; pc[idx * 16 + 8 + e] = dz[k][e] * xh[k][e]; }
+            }
+        }
+    }
+    const float inv_n = 1.f / (float)(HW * cg);
+    const float m1 = block_sum(s1, red[0]) * inv_n;       // (its barriers also publish pc)
+    const float m2 = block_sum(s2, red[1]) * inv_n;
+#pragma unroll
+    for (int k = 0; k < GNS_MAXCH; ++k) {
+        const int idx = threadIdx.x + 256 * k;
+        if (idx < n) {
+            const int row = idx / ncc, cc = idx - row * ncc;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(rstd * (gw[k][e] * dz[k][e] - m1 - xh[k][e] * m2));
+            if (dres) {
+                const bf16x8 rv = *(const bf16x8*)(dres + base + (size_t)row * C + cc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)o[e] + (float)rv[e]);
+            }
+            *(bf16x8*)(dx + base + (size_t)row * C + cc * 8) = o;
+        }
+    }
+    if (cpart) {
+        for (int t = threadIdx.x; t < 2 * cg; t += 256) {
+            const int which = t / cg, ch = t - which * cg, cc = ch >> 3, e = ch & 7;
+            float acc = 0.f;
+            for (int r = 0; r < HW; ++r) acc += pc[(r * ncc + cc) * 16 + which * 8 + e];
+            cpart[(size_t)b * 2 * C + (size_t)which * C + g * cg + ch] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row kept in registers (C <= 8*64*MAXCH).
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_MAXCH = 4;   // chunks of 8 per lane -> C <= 2048
@@ -398,6 +536,7 @@ static int gn_geometry(int HW, int C, int G, int* threads, int* rpar, int* rows_
     }
     *rows_per_block = rows;
     *strips = (HW + rows - 1) / rows;
+    if (gn_small(HW, C, G)) { *rows_per_block = HW; *strips = 1; }      // one workgroup per (group, sample) holds the slab
     return 0;
 }
 
@@ -419,6 +558,11 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
     hipStream_t st = (hipStream_t)stream;
     float* gpart = scratch;
     ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 3);
+    if (gn_small_fwd(HW, C, G)) {
+        hipLaunchKernelGGL(gn_small_fwd_kernel, dim3(G, B), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, stats,
+                           HW, C, G, silu, eps);
+        return mi355_check_launch("groupnorm_fwd(small)");
+    }
     const size_t sh = (size_t)threads * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x, nullptr,
                        nullptr, nullptr, nullptr, gpart, nullptr, HW, C, G, rows, 0);
@@ -439,6 +583,14 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
     float* gpart = scratch;
     float* cpart = scratch + (size_t)B * strips * G * 2;
     ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 5);
+    if (gn_small(HW, C, G)) {
+        const size_t shs = (size_t)HW * (C / G / 8) * 16 * sizeof(float);
+        hipLaunchKernelGGL(gn_small_bwd_kernel, dim3(G, B), dim3(256), shs, st, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma,
+                           beta, (bf16_t*)dx, cpart, (const bf16_t*)dres, HW, C, G, silu);
+        if (dgamma)
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B, 2 * C, dgamma, C);
+        return mi355_check_launch("groupnorm_bwd(small)");
+    }
     const size_t sh = (size_t)threads * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x,
                        (const bf16_t*)dy, stats, gamma, beta, gpart, cpart, HW, C, G, rows, silu);

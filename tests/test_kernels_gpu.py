@@ -162,7 +162,8 @@ def test_linear_backward(M, N, K):
 
 
 @pytest.mark.parametrize("B,HW,C,G,silu", [(2, 256, 320, 32, True), (3, 64, 640, 32, False), (2, 16, 2560, 32, True),
-                                           (2, 64, 64, 8, True), (1, 1024, 960, 32, True), (2, 49, 1920, 32, False)])
+                                           (2, 64, 64, 8, True), (1, 1024, 960, 32, True), (2, 49, 1920, 32, False),
+                                           (2, 64, 1280, 32, True), (4, 16, 1280, 32, False), (2, 64, 2560, 32, True), (2, 256, 1280, 32, True)])
 def test_groupnorm(B, HW, C, G, silu):
     from image_generator_amd.ops import GroupNormFn
     h = int(math.isqrt(HW))
