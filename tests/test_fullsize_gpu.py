@@ -1,0 +1,168 @@
+"""Full-size checks: the SD-v1 denoiser (859.5M parameters) on the benchmark workloads, where the fp32 CPU
+oracle would take minutes per step.  Every assertion is a property that holds at any size and can be evaluated
+in closed form from the step's own outputs:
+
+  train step (batch 32, 32x32 latents, T=77)
+    * d loss / d conv_out.bias[c] = 2/numel * sum(pred - noise)[:, c]        (the last layer is affine)
+    * a shift common to all channels of a GroupNorm group is invisible to the norm that follows, so the
+      conv1.bias gradient of every residual block sums to zero over each norm2 group, and it equals the
+      time_emb_proj.bias gradient (both are the per-channel sum of the same tensor)
+    * the recorded global gradient norm is the 2-norm of the flat gradient buffer
+    * a small plain gradient step lowers the re-evaluated loss by eta |g|^2 (directional derivative of the whole
+      backward pass)
+    * the first AdamW step from zero moments has the closed form
+          p1 = p0 (1 - lr wd) - (lr / (1-b1)) (1-b1) g' / (sqrt((1-b2) g'^2) / sqrt(1-b2) + eps),  g' = g * clip
+      and the bf16 operand copy is the round-to-nearest-even image of p1 (bit-exact)
+  sampler (64x64 latents = 512^2 images, classifier-free guidance)
+    * graph replay == eager launches, bit-exact
+    * identical conditional and unconditional text states make the guidance scale irrelevant
+    * a prompt sampled in a batch of two follows the same trajectory as sampled alone
+
+Tolerances are stated at each assertion (bf16 activations, fp32 accumulation).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def sd_unet():
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    torch.manual_seed(99)
+    with torch.device(D):
+        unet = UNet2DConditionModel(DenoiserConfig.sd_v1())
+    with torch.no_grad():       # biases / norm affine away from their trivial init
+        for p in unet.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    return unet
+
+
+def test_train_step_closed_form_properties(sd_unet):
+    from image_generator_amd.trainer import DenoiserTrainer
+    unet = sd_unet
+    assert sum(p.numel() for p in unet.parameters()) == 859_520_964
+    lr, wd, eps, b1, b2 = 1e-4, 1e-2, 1e-8, 0.9, 0.999
+    trainer = DenoiserTrainer(unet, lr=lr, weight_decay=wd, max_grad_norm=1.0)
+    B, L, T = 32, 32, 77
+    g = torch.Generator(device=D).manual_seed(7)
+    lat = torch.randn(B, 4, L, L, device=D, generator=g) * 0.9
+    noise = torch.randn(B, 4, L, L, device=D, generator=g)
+    ctx = torch.randn(B, T, 768, device=D, generator=g).to(torch.bfloat16)
+    ts = torch.randint(0, 1000, (B,), device=D, generator=g)
+
+    # the prediction of the same forward pass, for the closed-form last-layer gradient
+    with torch.no_grad():
+        noisy = trainer_noisy(trainer, lat, noise, ts)
+        pred = unet(noisy, ts, encoder_hidden_states=ctx).sample
+    p0 = trainer.opt.flat.clone()
+    loss = trainer.train_step(lat, noise, ts, ctx)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and abs(float(loss) - float(((pred - noise) ** 2).mean())) <= 2e-3 * float(loss)
+
+    # (1) last-layer bias gradient; 1e-2: the incoming gradient is rounded to bf16 once per element
+    want = 2.0 / pred.numel() * (pred - noise).double().sum(dim=(0, 2, 3))
+    got = unet.conv_out.bias.grad.double()
+    assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max()), (got, want)
+
+    # (2) GroupNorm shift invariance in every residual block
+    n_blocks = 0
+    for name, m in unet.named_modules():
+        if not (hasattr(m, "conv1") and hasattr(m, "norm2") and hasattr(m, "time_emb_proj")):
+            continue
+        n_blocks += 1
+        gb = m.conv1.bias.grad.double()
+        groups = gb.view(unet.config.norm_num_groups, -1)
+        # 2e-2 of the group's absolute mass: the summands are bf16-rounded per element before the channel sums
+        assert float((groups.sum(1).abs() / (groups.abs().sum(1) + 1e-30)).max()) <= 2e-2, name
+        assert _rel(m.time_emb_proj.bias.grad, gb) <= 1e-2, name
+    assert n_blocks == 22
+
+    # (3) recorded gradient norm == norm of the flat buffer (fp32 tree reduction against an fp64 one)
+    grad = trainer.opt.grad
+    gn = float(grad.double().norm())
+    assert gn > 0 and abs(trainer.opt.grad_norm() - gn) <= 1e-4 * gn
+
+    # (4) first AdamW step in closed form over all 859.5M parameters
+    clip = min(1.0, 1.0 / (trainer.opt.grad_norm() + 1e-6))      # the kernel clips by the norm it recorded
+    gg = grad * clip
+    m1, v1 = (1 - b1) * gg, (1 - b2) * gg * gg
+    denom = v1.sqrt() / (1 - b2) ** 0.5 + eps
+    p1 = p0 * (1 - lr * wd) - (lr / (1 - b1)) * (m1 / denom)
+    del gg, denom
+    err = (trainer.opt.flat - p1).abs()
+    # the update is lr * (+-1) wherever |g'| >> eps: allow 1e-3 of it plus fp32 rounding of p
+    assert float((err - 1e-6 * p1.abs()).max()) <= 1e-3 * lr, float(err.max())
+    assert _rel(trainer.opt.m, m1) <= 1e-5 and _rel(trainer.opt.v, v1) <= 1e-4     # v carries the clip factor squared
+    assert torch.equal(trainer.opt.flat16, trainer.opt.flat.to(torch.bfloat16))
+    moved = (trainer.opt.flat - p0).abs()
+    assert float(moved.max()) <= lr * (1 + 1e-3) + lr * wd * float(p0.abs().max())
+    assert float((moved > 0.5 * lr).float().mean()) > 0.9        # the step was taken everywhere, not skipped
+
+    # (5) directional derivative of the whole backward pass: a plain gradient step sized to lower the loss by 2 %
+    # (to first order, eta |g|^2) lowers the re-evaluated loss by that amount; within 35 % of it: curvature along
+    # the gradient plus ~1e-3 relative bf16 noise in each loss evaluation
+    loss0 = float(((pred - noise) ** 2).mean())
+    eta = 0.02 * loss0 / gn ** 2
+    with torch.no_grad():
+        trainer.opt.flat.copy_(p0 - eta * grad)
+        unet.refresh_operands(cast=True)
+        loss1 = float(((unet(noisy, ts, encoder_hidden_states=ctx).sample - noise) ** 2).mean())
+    drop = (loss0 - loss1) / (0.02 * loss0)
+    print(f"loss {loss0:.5f} -> {loss1:.5f}, measured/predicted decrease {drop:.3f}, |g| {gn:.4f}")
+    assert 0.65 <= drop <= 1.35, drop
+    for p in unet.parameters():
+        p.grad = None
+
+
+def trainer_noisy(trainer, lat, noise, ts):
+    from image_generator_amd._lib import lib, check
+    noisy = torch.empty_like(lat)
+    check(lib.mi355_ddpm_add_noise(lat.data_ptr(), noise.data_ptr(), ts.data_ptr(), trainer.acp.data_ptr(), noisy.data_ptr(),
+                                   lat.shape[0], lat[0].numel(), torch.cuda.current_stream().cuda_stream), "add_noise")
+    a = trainer.acp[ts].view(-1, 1, 1, 1)
+    assert _rel(noisy, a.sqrt() * lat + (1 - a).sqrt() * noise) <= 1e-6
+    return noisy
+
+
+def test_sampler_properties_at_512(sd_unet):
+    from image_generator_amd.generator import ImageGenerator
+    from image_generator_amd.schedulers import DDIMScheduler
+    unet = sd_unet.eval()
+    gen = ImageGenerator.__new__(ImageGenerator)          # the sampler loop alone: no text encoder / VAE needed
+    torch.nn.Module.__init__(gen)
+    gen.unet, gen.dtype, gen.infer_scheduler = unet, torch.float32, DDIMScheduler()
+    g = torch.Generator(device=D).manual_seed(11)
+    lat0 = torch.randn(2, 4, 64, 64, device=D, generator=g)
+    cond = torch.randn(2, 77, 768, device=D, generator=g).to(torch.bfloat16)
+    uncond = torch.randn(1, 77, 768, device=D, generator=g).to(torch.bfloat16).expand(2, -1, -1)
+    steps = 6
+
+    emb2 = torch.cat([uncond, cond]).contiguous()
+    eager = gen.sample_latents(emb2, lat0, steps, 7.5, use_graph=False)
+    graphed = gen.sample_latents(emb2, lat0, steps, 7.5, use_graph=True)
+    assert torch.isfinite(eager).all() and torch.equal(eager, graphed)
+
+    # each prompt alone follows the trajectory it has inside the batch (2e-2: the kernels may tile and split the
+    # two batch sizes differently, and 6 bf16 denoiser evaluations compound)
+    for i in range(2):
+        emb1 = torch.cat([uncond[i:i + 1], cond[i:i + 1]]).contiguous()
+        alone = gen.sample_latents(emb1, lat0[i:i + 1], steps, 7.5, use_graph=False)
+        assert _rel(alone, eager[i:i + 1]) <= 2e-2, (i, _rel(alone, eager[i:i + 1]))
+
+    # cond == uncond: eps_u + s (eps_c - eps_u) does not depend on s (2e-2: the two batch rows may differ in the
+    # last bf16 bit, which s = 7.5 amplifies)
+    same = torch.cat([cond[:1], cond[:1]]).contiguous()
+    a = gen.sample_latents(same, lat0[:1], steps, 1.0, use_graph=False)
+    b = gen.sample_latents(same, lat0[:1], steps, 7.5, use_graph=False)
+    assert _rel(b, a) <= 2e-2, _rel(b, a)
+    # and the guidance does matter when they differ
+    c = gen.sample_latents(torch.cat([uncond[:1], cond[:1]]).contiguous(), lat0[:1], steps, 1.0, use_graph=False)
+    assert _rel(c, eager[:1]) > 1e-3
