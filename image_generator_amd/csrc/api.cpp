@@ -58,6 +58,8 @@ void mi355_prof_end(int fam, hipStream_t s) {
 
 extern "C" {
 
+int mi355_zero_f32(float* p, long long n, void* stream);     // elementwise.hip
+
 const char* mi355_last_error(void) { return g_err; }
 
 int mi355_abi_version(void) { return 1; }
@@ -83,6 +85,32 @@ int mi355_prof_collect(double* ms, double* work, long long* count) {
     }
     g_recs.clear();
     return MI355_OK;
+}
+
+double mi355_prof_event_overhead_us(void* stream, float* scratch, long long scratch_floats, int n) {
+    if (!scratch || scratch_floats <= 0 || n <= 0 || n > 4096) { mi355_fail(MI355_ERR_ARG, "prof: bad calibration arguments"); return -1.0; }
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(2 * (size_t)n + 3, nullptr);
+    bool ok = true;
+    for (hipEvent_t& e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    hipEvent_t* outer = ev.data() + 2 * (size_t)n;
+    // n launches bare, then the same n with an event pair around each: the second run is longer by two event records
+    // per launch, of which the closing one falls inside its pair
+    ok = ok && hipEventRecord(outer[0], s) == hipSuccess;
+    for (int i = 0; ok && i < n; ++i) ok = mi355_zero_f32(scratch, scratch_floats, s) == MI355_OK;
+    ok = ok && hipEventRecord(outer[1], s) == hipSuccess;
+    for (int i = 0; ok && i < n; ++i) {
+        ok = hipEventRecord(ev[2 * i], s) == hipSuccess && mi355_zero_f32(scratch, scratch_floats, s) == MI355_OK &&
+             hipEventRecord(ev[2 * i + 1], s) == hipSuccess;
+    }
+    ok = ok && hipEventRecord(outer[2], s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    float bare = 0.f, paired = 0.f;
+    ok = ok && hipEventElapsedTime(&bare, outer[0], outer[1]) == hipSuccess &&
+         hipEventElapsedTime(&paired, outer[1], outer[2]) == hipSuccess;
+    for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
+    if (!ok) { mi355_fail(MI355_ERR_LAUNCH, "prof: event calibration failed"); return -1.0; }
+    const double us = ((double)paired - (double)bare) / (2.0 * n) * 1e3;
+    return us > 0.0 ? us : 0.0;
 }
 
 }  // extern "C"

@@ -947,6 +947,8 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     }
     const int nkt = (a.K + 63) / 64;
     int sk = a.geglu ? 1 : pick_splitk(a.tiles_m * a.tiles_n, nkt, (double)a.M * a.N, bn);
+    static const int force_sk = getenv("MI355_GEMM_SK") ? atoi(getenv("MI355_GEMM_SK")) : 0;     // tuning knob
+    if (force_sk > 0 && !a.geglu) sk = force_sk < nkt ? force_sk : nkt;
     while (sk > 1 && (size_t)sk * a.M * a.N * sizeof(float) > ws_bytes) --sk;
     a.kt_per_split = (nkt + sk - 1) / sk;
     sk = (nkt + a.kt_per_split - 1) / a.kt_per_split;

@@ -41,6 +41,12 @@ int mi355_abi_version(void);
  * Families: 0 gemm/conv, 1 weight-gradient, 2 attention, 3 normalisation, 4 elementwise. */
 int mi355_prof_enable(int on);
 int mi355_prof_collect(double* ms, double* work, long long* count);
+/* What one timed call carries besides its kernels, in microseconds: the stream's processing of the closing event.
+ * Measured as (n launches with an event pair around each - the same n launches bare) / 2n on `stream`; each launch
+ * clears `scratch_floats` device floats at `scratch` (size it so that one launch runs about as long as the timed
+ * kernels: part of an event's cost hides behind a running kernel).  Synchronises the stream; negative on failure.
+ * No counterpart in the reference (measurement aid). */
+double mi355_prof_event_overhead_us(void* stream, float* scratch, long long scratch_floats, int n);
 
 /* ---- contractions (image_generator.py:124: Linear / Conv2d layers of the denoiser) -------------
  * out[M][N] = alpha * A[M][K] . Bw[N][K]^T + bias[n] + rowbias[m / rowbias_div][n]

@@ -14,11 +14,16 @@ trace=$(find $out -name '*kernel_trace.csv' | head -1)
   echo "# bench line of the same (profiled) run:"
   grep -o '{"metric.*' $out/bench.log
   echo
-  echo "# per-kernel totals divided by the 13 graphed + 2 eager (event-timed) steps of the run (includes model init kernels)"
-  python tools/prof_summary.py $out 15 45
+  echo "# per-kernel totals divided by the 13 graphed + 3 eager steps of the run (includes model init kernels and the"
+  echo "# spin kernels that bench.py puts in front of its event-timed steps)"
+  python tools/prof_summary.py $out 16 45
   echo
   echo "# the last graph replay: window between its AdamW launch and the previous one (tools/graph_step_breakdown.py)"
-  python tools/graph_step_breakdown.py $trace 60 2 || true
+  python tools/graph_step_breakdown.py $trace 60 3 || true
+  echo
+  echo "# the last eager, event-timed step of the same run (what the bench line's roofline.families are measured on;"
+  echo "# the window starts with the spin kernel that lets the host run ahead)"
+  python tools/graph_step_breakdown.py $trace 60 0 || true
 } > $out/summary.txt
 cp $stats $out/kernel_stats.csv
 rm -f $trace
