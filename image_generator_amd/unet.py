@@ -738,10 +738,17 @@ class UNet2DConditionModel(nn.Module):
 
     # -------------------------------------------------------------------------------------------
     def forward(self, sample, timestep, encoder_hidden_states=None):
+        cfg = self.config
+        div = 1 << (len(cfg.block_out_channels) - 1)
+        if sample.dim() != 4 or sample.shape[1] != cfg.in_channels or sample.shape[2] % div or sample.shape[3] % div:
+            # every level halves the map and the skip connections are concatenated without resampling
+            raise ValueError(f"UNet2DConditionModel: expected [B, {cfg.in_channels}, H, W] with H and W multiples of {div}, "
+                             f"got {tuple(sample.shape)}")
+        if encoder_hidden_states is None or encoder_hidden_states.shape[-1] != cfg.cross_attention_dim:
+            raise ValueError(f"UNet2DConditionModel: encoder_hidden_states [B, T, {cfg.cross_attention_dim}] required")
         if not sample.is_cuda:
             raise RuntimeError("UNet2DConditionModel: HIP device tensors required (no CPU path)")
         self._maybe_refresh()
-        cfg = self.config
         B = sample.shape[0]
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], device=sample.device)

@@ -40,6 +40,11 @@ def test_product_fails_loudly_on_cpu_tensors():
         m(torch.randn(1, 4, 8, 8), torch.tensor([1]), torch.randn(1, 4, 64))
     with pytest.raises(RuntimeError):
         ContrastiveLoss()(torch.randn(4, 8), torch.randn(4, 8))
+    # shapes the level structure cannot carry are named, not left to a concatenation error deep in the up path
+    with pytest.raises(ValueError, match="multiples of 4"):
+        m(torch.randn(1, 4, 10, 8), torch.tensor([1]), torch.randn(1, 4, 64))
+    with pytest.raises(ValueError, match="encoder_hidden_states"):
+        m(torch.randn(1, 4, 8, 8), torch.tensor([1]), torch.randn(1, 4, 32))
 
 
 def test_denoiser_state_dict_is_checkpoint_compatible():

@@ -54,7 +54,9 @@ def _cos(a, b):
     return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("cfg_name,B,hw,T", [("small", 4, 8, 16), ("small", 2, 16, 7), ("sdlike", 2, 16, 77)])
+# ragged cases: one sample, one context token, maps of 12x12 / 20x20 (levels 6x6, 3x3 / 10x10, 5x5: no tile is full)
+@pytest.mark.parametrize("cfg_name,B,hw,T", [("small", 4, 8, 16), ("small", 2, 16, 7), ("sdlike", 2, 16, 77),
+                                             ("small", 1, 12, 1), ("small", 3, 20, 5)])
 def test_unet_forward_backward_parity(cfg_name, B, hw, T):
     from oracle.denoiser_ref import mse_objective
     from image_generator_amd.ops import mse_loss
@@ -69,11 +71,16 @@ def test_unet_forward_backward_parity(cfg_name, B, hw, T):
     loss = mse_loss(out, noise.to(d))
     loss.backward()
     assert _rel(out, out_ref) <= 2e-2, _rel(out, out_ref)
-    assert abs(float(loss) - float(loss_ref)) <= 1e-2 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-2 * abs(float(loss_ref.detach())), (float(loss.detach()), float(loss_ref.detach()))
     rp = dict(ref.named_parameters())
     cosines = []
     for n, p in hip.named_parameters():
         assert p.grad is not None, n
+        if float(rp[n].grad.norm()) < 1e-12:
+            # one context token: softmax over a single key is 1, so nothing upstream of the cross-attention query has a
+            # gradient; the HIP path must produce (numerically) nothing there either
+            assert float(p.grad.float().norm()) <= 1e-6, (n, float(p.grad.float().norm()))
+            continue
         c, r = _cos(p.grad, rp[n].grad), _rel(p.grad, rp[n].grad)
         cosines.append(c)
         assert c >= 0.98 and r <= 0.2, (n, c, r)
