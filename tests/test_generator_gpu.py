@@ -426,3 +426,49 @@ def test_vae_matches_oracle_and_checkpoint_layout():
     assert rel_o <= 3e-2, rel_o
     g1, g2 = torch.Generator(device=D).manual_seed(5), torch.Generator(device=D).manual_seed(5)
     assert torch.equal(dist.sample(g1), dist.mean + dist.std * torch.randn(dist.mean.shape, generator=g2, device=D))
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_training_trajectory_follows_oracle_optimizer(graphed):
+    """Ten steps of the fused trainer (clip to norm 1, AdamW lr 2e-4 / wd 1e-2, noise and timesteps redrawn per step) against
+    the fp32 CPU oracle trained with torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW from the same weights:
+    every step's loss within 5e-3 relative and pre-clip gradient norm within 1e-2 (measured: 5e-4 and 4e-3; Adam's
+    normalised update amplifies small gradient differences on near-zero gradients, so the weights are compared
+    through the losses and gradient norms they produce).  Run eagerly and as the replayed whole-step HIP graph."""
+    from oracle import ops_ref
+    from oracle.denoiser_ref import DenoiserRef, DenoiserConfig as RC, mse_objective
+    from image_generator_amd.trainer import DenoiserTrainer
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    torch.manual_seed(21)
+    ref = DenoiserRef(RC.small())
+    hip = UNet2DConditionModel(DenoiserConfig.small())
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(D)
+    lr, wd, steps, B = 2e-4, 1e-2, 10, 4
+    trainer = DenoiserTrainer(hip, lr=lr, weight_decay=wd, max_grad_norm=1.0)
+    opt = torch.optim.AdamW(ref.parameters(), lr=lr, weight_decay=wd)
+    acp = ops_ref.sd_alphas_cumprod()
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(B, 4, 8, 8, generator=g)             # a small fixed data set the model can fit
+    ctx = torch.randn(B, 9, 64, generator=g)
+    batches = [(base, torch.randn(B, 4, 8, 8, generator=g), torch.randint(0, 1000, (B,), generator=g)) for _ in range(steps)]
+    dev = [(l.to(D), n.to(D), t.to(D)) for l, n, t in batches]
+    ctx_d = ctx.to(D).to(torch.bfloat16)
+    if graphed:
+        trainer.capture(*dev[0], ctx_d)
+    losses, losses_ref, norms = [], [], []
+    for i in range(steps):
+        lat, noise, t = batches[i]
+        opt.zero_grad(set_to_none=True)
+        lref = mse_objective(ref(ops_ref.ddpm_add_noise(lat, noise, t, acp), t, ctx.to(torch.bfloat16).float()).sample, noise)
+        lref.backward()
+        gref = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0))
+        opt.step()
+        losses_ref.append(float(lref.detach()))
+        losses.append(float(trainer.train_step(*dev[i], ctx_d)))
+        norms.append((trainer.opt.grad_norm(), gref))
+    print("loss hip", [round(x, 4) for x in losses], "\nloss ref", [round(x, 4) for x in losses_ref], "\nnorms", norms)
+    for i, (a, b) in enumerate(norms):
+        assert abs(a - b) <= 1e-2 * b, (i, norms)
+    for i, (a, b) in enumerate(zip(losses, losses_ref)):
+        assert abs(a - b) <= 5e-3 * b, (i, losses, losses_ref)
