@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--ctx-len", type=int, default=77)
     ap.add_argument("--prof-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU oracle step (32 = the GPU step's own batch, ~15 s on 16 cores)")
     ap.add_argument("--small", action="store_true", help="plumbing-size model (NOT the headline config)")
     ap.add_argument("--no-graph", action="store_true", help="run the eager step even on one GPU")
     ap.add_argument("--lora", action="store_true",
