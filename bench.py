@@ -172,9 +172,17 @@ def main():
         if prof:
             gp = prof["gemm_conv"]
             tf = gp["work_per_step"] / (gp["ms_per_step"] * 1e-3) / 1e12 if gp["ms_per_step"] > 0 else 0.0
+            # HBM-side bytes of the same family from the committed rocprofv3 --pmc passes over this workload
+            # (tools/pmc_step.sh: counters cannot be read from inside the process), per library call like `achieved`
+            traffic, traffic_src = None, None
+            tf_path = os.path.join(ROOT, "profiles", "r01_pmc", "step_traffic.json")
+            if os.path.exists(tf_path) and not args.small and not args.lora and B == 32 and L == 32:
+                fam = json.load(open(tf_path))["families"]["gemm_conv"]
+                traffic = (fam["fetch_bytes_per_step"] + fam["write_bytes_per_step"]) / max(1.0, gp["launches_per_step"])
+                traffic_src = "profiles/r01_pmc/step_traffic.json (separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE, bytes per call)"
             roof = {"bound": "mfma", "kernel": "gemm_dma_kernel family (implicit-GEMM conv + linear, fwd and dgrad)",
                     "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
-                    "traffic": None, "event_pair_overhead_us": pair_us,
+                    "traffic": traffic, "traffic_source": traffic_src, "event_pair_overhead_us": pair_us,
                     "avg_launch_us": gp["ms_per_step"] * 1e3 / max(1.0, gp["launches_per_step"]),
                     "flops_per_launch": gp["work_per_step"] / max(1.0, gp["launches_per_step"]),
                     "families": {f: {"ms_per_step": round(p["ms_per_step"], 3), "raw_ms_per_step": round(p["raw_ms_per_step"], 3),
