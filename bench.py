@@ -167,6 +167,26 @@ def main():
             raw = msv[i] / args.prof_steps
             prof[f] = {"ms_per_step": max(raw - pair_us * 1e-3 * cnt[i] / args.prof_steps, 0.5 * raw), "raw_ms_per_step": raw,
                        "work_per_step": work[i] / args.prof_steps, "launches_per_step": cnt[i] / args.prof_steps}
+    measured = None
+    if rank == 0 and not args.small:
+        # what this device sustains, beside the spec figures the fractions are quoted against: register-only bf16 MFMA
+        # loops on pseudo-random operands (the clock the chip holds depends on the data) and a 1 GiB streaming copy
+        def _timed(fn, n):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / n * 1e-3
+        cs = torch.cuda.current_stream().cuda_stream
+        sink = torch.zeros(4, device=dev)
+        it = 80000
+        t = _timed(lambda: lib.mi355_peak_mfma_bf16(sink.data_ptr(), 256, it, 1, cs), 20)
+        src, dst = torch.ones(1 << 30, dtype=torch.uint8, device=dev), torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        tc = _timed(lambda: lib.mi355_peak_copy(src.data_ptr(), dst.data_ptr(), 1 << 30, cs), 10)
+        measured = {"mfma_bf16_random_operands_TFLOPs": 256 * 4 * it * 8 * 16384 / t / 1e12, "copy_1GiB_TBs": 2 * (1 << 30) / tc / 1e12}
+        del src, dst
     if rank == 0:
         roof = None
         if prof:
@@ -183,6 +203,8 @@ def main():
             roof = {"bound": "mfma", "kernel": "gemm_dma_kernel family (implicit-GEMM conv + linear, fwd and dgrad)",
                     "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "event_pair_overhead_us": pair_us,
+                    "measured_on_this_device": measured,
+                    "frac_of_measured_mfma": (tf / measured["mfma_bf16_random_operands_TFLOPs"]) if measured else None,
                     "avg_launch_us": gp["ms_per_step"] * 1e3 / max(1.0, gp["launches_per_step"]),
                     "flops_per_launch": gp["work_per_step"] / max(1.0, gp["launches_per_step"]),
                     "families": {f: {"ms_per_step": round(p["ms_per_step"], 3), "raw_ms_per_step": round(p["raw_ms_per_step"], 3),

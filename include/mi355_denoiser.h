@@ -48,6 +48,14 @@ int mi355_prof_collect(double* ms, double* work, long long* count);
  * No counterpart in the reference (measurement aid). */
 double mi355_prof_event_overhead_us(void* stream, float* scratch, long long scratch_floats, int n);
 
+/* What the GPU sustains on the two resources the kernels are priced against (measurement aids, no counterpart in the
+ * reference; nothing in the product calls them).
+ * peak_mfma: `blocks` workgroups of four waves each issue `iters` rounds of eight independent v_mfma_f32_16x16x32_bf16
+ * on registers only (iters a multiple of 8): flops = blocks * 4 * iters * 8 * 16384.  pattern 0: zero operands, 1: mixed-sign changing values.
+ * peak_copy: 16-byte-per-lane streaming copy, traffic = 2 * bytes (bytes and both pointers multiples of 16). */
+int mi355_peak_mfma_bf16(float* sink, int blocks, int iters, int pattern, void* stream);
+int mi355_peak_copy(const void* src, void* dst, long long bytes, void* stream);
+
 /* ---- contractions (image_generator.py:124: Linear / Conv2d layers of the denoiser) -------------
  * out[M][N] = alpha * A[M][K] . Bw[N][K]^T + bias[n] + rowbias[m / rowbias_div][n]
  *             + lora_alpha * (lora_t[m][:] . lora_b[n][:]) + residual[m][n]
