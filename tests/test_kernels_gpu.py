@@ -554,3 +554,32 @@ def test_gemm_skinny(M, K, W):
     out = ops.gemm_skinny(a.to(dev()), w.to(dev()), 0.5)
     ref = 0.5 * (a.float() @ w.float().t())
     close(out, ref, 2 ** -7, 1e-2, f"skinny {M}x{W}x{K}")
+
+
+def test_measurement_aids():
+    """The measurement entry points do what their arithmetic says: the streaming copy copies (ragged tail included), the
+    MFMA loop runs and reports a rate between a tenth of and the whole spec peak, the event-overhead probe returns a
+    few microseconds, and bad arguments are refused."""
+    from image_generator_amd.ops import lib, check, _stream
+    d = dev()
+    n = (1 << 20) + 16 * 37
+    src = torch.randint(0, 255, (n,), dtype=torch.uint8, device=d)
+    dst = torch.zeros(n, dtype=torch.uint8, device=d)
+    check(lib.mi355_peak_copy(src.data_ptr(), dst.data_ptr(), n, _stream()))
+    assert torch.equal(src, dst)
+    assert lib.mi355_peak_copy(src.data_ptr(), dst.data_ptr(), n - 3, _stream()) != 0
+    sink = torch.zeros(4, device=d)
+    assert lib.mi355_peak_mfma_bf16(sink.data_ptr(), 256, 12, 1, _stream()) != 0          # iters not a multiple of 8
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    check(lib.mi355_peak_mfma_bf16(sink.data_ptr(), 256, 8000, 1, _stream()))
+    e0.record()
+    check(lib.mi355_peak_mfma_bf16(sink.data_ptr(), 256, 80000, 1, _stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    tf = 256 * 4 * 80000 * 8 * 16384 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    assert 250.0 < tf < 2600.0, tf
+    assert float(sink.abs().sum()) == 0.0
+    cal = torch.zeros(1 << 20, device=d)
+    us = lib.mi355_prof_event_overhead_us(_stream(), cal.data_ptr(), cal.numel(), 64)
+    assert 0.0 <= us < 100.0, us
+    assert lib.mi355_prof_event_overhead_us(_stream(), None, 8, 64) < 0
