@@ -473,7 +473,10 @@ constexpr int OOB_OFF = (int)0x80000000;
 // BM: rows per tile.  (256 rows with 8 waves as ONE workgroup per CU measured 15 % slower than two 128-row
 // workgroups: its waves run barrier-locked, so DMA issue and MFMA phases never overlap.  Large grids use
 // gemm_wide_kernel instead.)
-template <int BN, int AMODE, int NW = 4, int BM = 128>
+// NST: LDS stages.  3 (grids of at most one workgroup per CU, which have the LDS to spare): tile kt + 2 is requested
+// while tile kt is multiplied, so a request has two iterations to land instead of one - with one workgroup per CU the
+// 2-stage loop waits on every tile's round trip (~1 600 cycles per k-tile against 640 of MFMA).
+template <int BN, int AMODE, int NW = 4, int BM = 128, int NST = 2>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the body uses device-only buffer-resource builtins
     constexpr int BK = 64;
@@ -581,13 +584,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
-    if (kt_begin < kt_end) issue(kt_begin, 0);
+    // NST stages: tiles kt + 1 .. kt + NST - 2 stay in flight while tile kt is multiplied
+#pragma unroll
+    for (int d = 0; d < NST - 1; ++d)
+        if (kt_begin + d < kt_end) issue(kt_begin + d, d);
     int cur = 0;
+    // requests complete in order: wait until only the newer tiles' can be outstanding (the waves with the fewest
+    // pieces per tile have PER_TILE of them)
+    constexpr int PER_TILE = A_P + (B_PIECES % NW == 0 ? B_P : B_P - 1);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed
+        if (NST >= 3 && kt + NST - 2 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER_TILE) : "memory");
+        else if (NST == 4 && kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of tile kt have landed
         __builtin_amdgcn_s_barrier();                         // everyone's have; everyone left tile kt-1
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);          // in flight under the MFMAs below
+        // the next request goes into the stage tile kt-1 was read from
+        if (kt + NST - 1 < kt_end) issue(kt + NST - 1, cur == 0 ? NST - 1 : cur - 1);
         const char* As = smem + cur * STAGE;
         const char* Bs = As + BM * 128;
 #pragma unroll
@@ -610,7 +622,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        cur ^= 1;
+        cur = cur == NST - 1 ? 0 : cur + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -890,6 +902,19 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
     const int grid = a.tiles_m * a.tiles_n * a.splitk;
     // measured on the denoiser step: 8 waves win up to two workgroups per CU, 4 waves beyond
     static const int nw8_max = getenv("MI355_GEMM_NW8") ? atoi(getenv("MI355_GEMM_NW8")) : 512;
+    // at most one workgroup per CU: the LDS for a third stage is free (110 KB of the CU's 160 KB); a fourth (147 KB)
+    // measured 0.1 ms/step slower than three
+    static const int nst3_max = getenv("MI355_GEMM_NST3") ? atoi(getenv("MI355_GEMM_NST3")) : 256;
+    if (grid <= nst3_max && grid <= nw8_max) {
+        constexpr int smem3 = 3 * (128 + BN) * 128;
+        static bool attr83_set = false;
+        if (!attr83_set) {
+            hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+            attr83_set = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8, 128, 3>), dim3(grid), dim3(512), smem3, s, a, a_bytes, b_bytes);
+        return mi355_check_launch("gemm_dma_kernel<8 waves, 3 stages>");
+    }
     if (grid <= nw8_max) {
         static bool attr8_set = false;
         if (!attr8_set) {
@@ -904,7 +929,7 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
 }
 
 static int pick_splitk(int tiles, int nkt, double out_elems, int bn) {
-    const int capacity = 512;
+    static const int capacity = getenv("MI355_GEMM_SK_CAP") ? atoi(getenv("MI355_GEMM_SK_CAP")) : 512;
     const double t_tile = (bn == 160 ? 1.0 : bn == 128 ? 0.8 : 0.45);
     int best = 1;
     double best_t = 1e30;
