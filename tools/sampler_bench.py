@@ -1,4 +1,4 @@
-"""BASELINE configs 4 and 5 on one MI355X (run on the GPU box):
+"""The LoRA fine-tune step and the 512x512 sampling loop on one MI355X (run on the GPU box):
   --mode sampler : 512x512 sampling loop, 16 images with classifier-free guidance (UNet batch 32), DDIM,
                    one HIP graph per step shape; reports sampler steps/s and the MFMA fraction
                    (25.7 TFLOP per step: 32 x 803.9 GFLOP forward at 64x64 latents)
