@@ -297,6 +297,31 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
+// table[2r], table[2r+1]: address and float count of range r; a NEGATIVE count marks values that are already partial sums
+// (added as they are).  grid (blocks per range, ranges).
+__global__ __launch_bounds__(256) void sumsq_ranges_kernel(const long long* __restrict__ table, float* __restrict__ out) {
+    __shared__ float red[16];
+    const float* g = (const float*)table[2 * blockIdx.y];
+    long long n = table[2 * blockIdx.y + 1];
+    const bool plain = n < 0;
+    if (plain) n = -n;
+    float s = 0.f;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    if (plain) {
+        for (long long i = i0; i < n; i += stride) s += g[i];
+    } else if ((((uintptr_t)g) & 15) == 0) {
+        const long long n4 = n >> 2;
+        for (long long i = i0; i < n4; i += stride) {
+            const f32x4 v = *(const f32x4*)(g + i * 4);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        if (i0 < (n & 3)) { const float v = g[n4 * 4 + i0]; s += v * v; }
+    } else {
+        for (long long i = i0; i < n; i += stride) s += g[i] * g[i];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(out, s);
+}
 __global__ __launch_bounds__(256) void sumsq_bf16_kernel(const bf16_t* __restrict__ g, float* __restrict__ out, size_t n8) {
     __shared__ float red[16];
     float s = 0.f;
@@ -795,6 +820,12 @@ int mi355_sumsq_f32(const float* g, float* out, long long n, void* stream) {
     ProfScope prof(FAM_ELEM, ST, (double)n * 4);
     hipLaunchKernelGGL(sumsq_kernel, dim3(GRID_FOR(n / 4 + 1, 1024)), dim3(256), 0, ST, g, out, (size_t)n);
     return mi355_check_launch("sumsq");
+}
+// out += sum over the table's ranges (see sumsq_ranges_kernel): the parts of a gradient buffer that no producer summed.
+int mi355_sumsq_ranges(const long long* table, int n, float* out, void* stream) {
+    if (!table || !out || n <= 0) return mi355_fail(MI355_ERR_ARG, "sumsq_ranges: bad arguments");
+    hipLaunchKernelGGL(sumsq_ranges_kernel, dim3(128, n), dim3(256), 0, ST, table, out);
+    return mi355_check_launch("sumsq_ranges");
 }
 int mi355_sumsq_bf16(const void* g, float* out, long long n, void* stream) {
     if (!g || !out || (n & 7)) return mi355_fail(MI355_ERR_ARG, "sumsq_bf16: null pointer or n not a multiple of 8");

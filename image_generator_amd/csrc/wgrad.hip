@@ -27,6 +27,8 @@ struct WgradArgs {
     unsigned dy_bytes, x_bytes;   // extents of dy / x for the LDS-DMA loader's buffer descriptors (< 2 GiB)
     int lw, lh;         // log2(Wo), log2(Ho) when both are powers of two, else -1
     int nmain;          // LDS-DMA launch: number of workgroups that have work (a grouped launch pads each job)
+    float* sumsq;       // optional 64 fp32 slots: unsplit jobs add the sum of squares of what they store (the global
+                        // gradient norm then needs no second pass over these gradients)
 };
 
 constexpr int WG_BT = 160;          // channels per tile side
@@ -457,6 +459,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int blo
     }
 
     const int ktot = p.taps * p.Cin;
+    float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -468,9 +471,13 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int blo
                 if (co < p.Cout && ci < p.Cin) {
                     float* dst = p.dw + (size_t)co * ktot + (size_t)tap * p.Cin + ci;
                     if (p.use_atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
-                    else *dst = acc[i][j][r];
+                    else { *dst = acc[i][j][r]; sq += acc[i][j][r] * acc[i][j][r]; }
                 }
             }
+    if (p.sumsq != nullptr && !p.use_atomic) {
+        sq = wave_sum(sq);
+        if (lane == 0) atomicAdd(p.sumsq + ((block_id * 4 + wave) & 63), sq);
+    }
 #endif
 }
 
@@ -608,7 +615,7 @@ int mi355_wgrad_job_bytes(void) { return (int)sizeof(WgradJob); }
 // number of blocks the job occupies in the grouped launch (a multiple of 8), or a negative error.
 int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W,
                          int Cin, int Cout, int ksize, int stride, int ups, int Ho, int Wo, int first_block,
-                         int* splits_out) {
+                         int* splits_out, float* sumsq_slots) {
     if (!host_job || !dy || !x || !dw) return mi355_fail(MI355_ERR_ARG, "wgrad_job_fill: null pointer");
     if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "wgrad_job_fill: ksize %d", ksize);
     if ((Cin & 7) || (Cout & 7)) return mi355_fail(MI355_ERR_ARG, "wgrad_job_fill: channels must be multiples of 8");
@@ -627,6 +634,7 @@ int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* d
         a.splits = (nkt + a.kt_per_split - 1) / a.kt_per_split;
     }
     a.use_atomic = a.splits > 1 ? 1 : 0;
+    a.sumsq = a.use_atomic ? nullptr : sumsq_slots;
     const int blocks = wgrad_dma_blocks(a);
     j->first_block = first_block;
     j->nblocks = (blocks + 7) & ~7;

@@ -169,12 +169,24 @@ class WgradQueue:
         # flush) when `zero_split_outputs` is set, so the owner need not clear the whole gradient buffer every step
         self.zero_split_outputs = False
         self._zero = []
+        # `track_sumsq(slots, lo, hi)`: unsplit jobs whose destination lies in [lo, hi) add the sum of squares of what they
+        # store to `slots` (64 floats) and are listed in `covered` (address, floats) for the owner of the gradient norm
+        self._sq_slots, self._sq_lo, self._sq_hi = None, 0, 0
+        self.covered = []
+
+    def track_sumsq(self, slots, lo=0, hi=0):
+        self._sq_slots, self._sq_lo, self._sq_hi = (None if slots is None else slots.data_ptr()), lo, hi
+        self.covered = []
 
     def push(self, dy, x, dw, dbias, B, H, W, cin, cout, ksize, stride, ups, Ho, Wo, callback=None):
+        dwp = dw.data_ptr()
+        slots = self._sq_slots if (self._sq_slots is not None and self._sq_lo <= dwp < self._sq_hi) else None
         nb = lib.mi355_wgrad_job_fill(self._host.data_ptr() + self._n * self.jb, dy.data_ptr(), x.data_ptr(),
-                                      dw.data_ptr(), _ptr(dbias), B, H, W, cin, cout, ksize, stride, int(ups), Ho, Wo,
-                                      self._blocks, ctypes.byref(self._splits))
+                                      dwp, _ptr(dbias), B, H, W, cin, cout, ksize, stride, int(ups), Ho, Wo,
+                                      self._blocks, ctypes.byref(self._splits), slots)
         check(min(nb, 0), "wgrad_job_fill")
+        if slots is not None and self._splits.value == 1:
+            self.covered.append((dwp, cout * ksize * ksize * cin))
         if self.zero_split_outputs and self._splits.value > 1:
             self._zero.append((dw.data_ptr(), dw.numel() * 4))
         self._n += 1

@@ -147,6 +147,9 @@ class FusedAdamW:
         dev = self.flat.device
         self.hyper = torch.zeros(9, dtype=F32, device=dev)
         self.state = torch.zeros(2, dtype=F32, device=dev)
+        # 64 partial sums of squares that unsplit weight-gradient jobs add to while they store their results
+        self.sq_slots = torch.zeros(64, dtype=F32, device=dev)
+        self._sq_tables = {}
         self._hyper_ring = [torch.zeros(9, dtype=F32).pin_memory() for _ in range(8)]
 
     def set_hyper(self, lr=None, grad_prescale=1.0):
@@ -160,12 +163,49 @@ class FusedAdamW:
         h[7], h[8] = self.max_norm if self.max_norm else 0.0, grad_prescale
         self.hyper.copy_(h, non_blocking=True)
 
-    def apply(self, grad16=None):
+    def _uncovered_table(self, covered):
+        """Device table for `mi355_sumsq_ranges`: the parts of the flat gradient buffer outside `covered` (address,
+        floats of weight gradients whose sums of squares are already in `sq_slots`), then the slots themselves.
+        Tables are kept for the life of the optimizer (a captured step re-reads its table on every replay)."""
+        key = tuple(covered)
+        hit = self._sq_tables.get(key)
+        if hit is not None:
+            return hit
+        lo = self.grad.data_ptr()
+        hi = lo + 4 * self.grad.numel()
+        rows, cur = [], lo
+        for ptr, cnt in sorted(covered):
+            if ptr < cur or ptr + 4 * cnt > hi:
+                raise RuntimeError("FusedAdamW: overlapping or out-of-range weight-gradient destinations")
+            if ptr > cur:
+                rows.append((cur, (ptr - cur) // 4))
+            cur = ptr + 4 * cnt
+        if cur < hi:
+            rows.append((cur, (hi - cur) // 4))
+        rows.append((self.sq_slots.data_ptr(), -self.sq_slots.numel()))
+        host = torch.tensor(rows, dtype=torch.int64)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FusedAdamW: the range table of a captured step must be built by an eager step first")
+        table = host.to(self.flat.device)
+        self._sq_tables[key] = (table, len(rows))
+        return self._sq_tables[key]
+
+    def apply(self, grad16=None, covered=None):
         """The device-side part of the step (capturable).  grad16: bf16 gradients laid out like the flat buffer (the
-        all-reduced staging buffer of a data-parallel step) to use instead of the fp32 ones."""
+        all-reduced staging buffer of a data-parallel step) to use instead of the fp32 ones.  covered: (address, floats)
+        of the gradients whose sums of squares the weight-gradient launches left in `sq_slots`; the norm pass then reads
+        only the rest of the buffer."""
         s = _stream()
         n = self.flat.numel()
         check(lib.mi355_zero_f32(self.state.data_ptr(), 2, s), "zero")
+        if covered and grad16 is None:
+            table, rows = self._uncovered_table(covered)
+            check(lib.mi355_sumsq_ranges(table.data_ptr(), rows, self.state.data_ptr(), s), "sumsq_ranges")
+            check(lib.mi355_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                       self.flat16.data_ptr(), self.hyper.data_ptr(), self.state.data_ptr(), n, s), "adamw")
+            if not self.frozen_base:
+                self.unet.refresh_operands(cast=False)
+            return
         if grad16 is not None and n % 8 == 0:
             assert grad16.numel() == n and grad16.dtype == BF16
             check(lib.mi355_sumsq_bf16(grad16.data_ptr(), self.state.data_ptr(), n, s), "sumsq_bf16")
@@ -181,9 +221,9 @@ class FusedAdamW:
         if not self.frozen_base:          # a frozen base keeps its operand copies; the adapters are read as fp32 masters
             self.unet.refresh_operands(cast=False)
 
-    def step(self, lr=None, grad_prescale=1.0, grad16=None):
+    def step(self, lr=None, grad_prescale=1.0, grad16=None, covered=None):
         self.set_hyper(lr, grad_prescale)
-        self.apply(grad16)
+        self.apply(grad16, covered)
 
     def grad_norm(self):
         """Host read of the last step's pre-clip global gradient norm (synchronises)."""
@@ -264,6 +304,11 @@ class DenoiserTrainer:
             self.wgrad_queue.zero_split_outputs = True
         # norm-layer parameter gradients: one batched reduction per step instead of one launch per layer
         self.reduce_queue = _ops.ReduceQueue(dev) if os.environ.get("MI355_NO_REDUCE_QUEUE") != "1" else None
+        # single-process full fine-tune: unsplit weight-gradient jobs sum their squares while they store, and the
+        # optimizer's norm pass skips those gradients (most of the 3.4 GB buffer)
+        self._fused_sumsq = (self.wgrad_queue is not None and self.reducer is None and not self.opt.frozen_base
+                             and os.environ.get("MI355_NO_FUSED_SUMSQ") != "1")
+        self._covered = None
 
     def forward_backward(self, latents, noise, t, ctx):
         B = latents.shape[0]
@@ -272,6 +317,12 @@ class DenoiserTrainer:
                                        noisy.data_ptr(), B, latents[0].numel(), _stream()), "ddpm_add_noise")
         # with the queue, pixel-split weight gradients are cleared per job and unsplit ones are plain stores
         self.unet.zero_small_grads(weights_too=self.wgrad_queue is None)
+        fused = self._fused_sumsq and self.wgrad_queue is not None
+        self._covered = None
+        if fused:
+            g = self.opt.grad
+            check(lib.mi355_zero_f32(self.opt.sq_slots.data_ptr(), 64, _stream()), "zero")
+            self.wgrad_queue.track_sumsq(self.opt.sq_slots, g.data_ptr(), g.data_ptr() + 4 * g.numel())
         pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
         loss = mse_loss(pred, noise)
         self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched
@@ -280,9 +331,12 @@ class DenoiserTrainer:
             loss.backward()
             if self.wgrad_queue is not None:
                 self.wgrad_queue.join()
+                self._covered = list(self.wgrad_queue.covered) if fused else None
             if self.reduce_queue is not None:
                 self.reduce_queue.flush()
         finally:
+            if fused:
+                self.wgrad_queue.track_sumsq(None)
             self._ops.set_wgrad_queue(None)
             self._ops.set_reduce_queue(None)
         self.unet.finish_grads()
@@ -296,7 +350,7 @@ class DenoiserTrainer:
             return self._replay(latents, noise, t, ctx, lr)
         loss = self.forward_backward(latents, noise, t, ctx)
         reduced = self.reducer.stage_all if (self.reducer is not None and self.reducer.active) else None
-        self.opt.step(lr=lr, grad_prescale=1.0 / self.world, grad16=reduced)
+        self.opt.step(lr=lr, grad_prescale=1.0 / self.world, grad16=reduced, covered=self._covered)
         self.step_count += 1
         return loss
 
@@ -365,7 +419,7 @@ class DenoiserTrainer:
             for _ in range(2):
                 opt.lr, opt.wd = 0.0, 0.0
                 self.forward_backward(*self._static)
-                opt.step(lr=0.0, grad_prescale=1.0)
+                opt.step(lr=0.0, grad_prescale=1.0, covered=self._covered)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         opt.lr, opt.wd = keep
@@ -375,7 +429,7 @@ class DenoiserTrainer:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_loss = self.forward_backward(*self._static)
-            opt.apply()
+            opt.apply(covered=self._covered)
         self._graph = g
 
     def _replay(self, latents, noise, t, ctx, lr):

@@ -106,11 +106,14 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
 
 /* Deferred, batched weight gradients: fill job records on the host, copy them to the device, launch once.
  * mi355_wgrad_job_fill returns the job's block count (multiple of 8); first_block = running sum of them.
- * dw/dbias of every job must be zero before the launch (split jobs and bias sums accumulate atomically). */
+ * dw/dbias of every job must be zero before the launch (split jobs and bias sums accumulate atomically).
+ * sumsq_slots (optional, 64 device floats, zeroed by the caller): a job that is NOT pixel-split (*splits_out == 1)
+ * adds the sum of squares of the dw it stores to these slots, so the global gradient norm of the optimizer
+ * (trainer.py:257) needs no second pass over that gradient; split jobs ignore it. */
 int mi355_wgrad_job_bytes(void);
 int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W,
                          int Cin, int Cout, int ksize, int stride, int ups, int Ho, int Wo, int first_block,
-                         int* splits_out);
+                         int* splits_out, float* sumsq_slots);
 int mi355_wgrad_grouped(const void* jobs, int njobs, int total_blocks, double flops, void* stream);
 
 /* out[s][n] = sum of the rows of segment s (seg rows each) of y[M][N] (bias / broadcast gradients). */
@@ -195,6 +198,10 @@ int mi355_ddim_step_cfg(const float* eps, const float* x, float* out, const floa
  * hyper (device floats): lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_grad_norm,
  * grad pre-scale.  state (device floats): [0] = sum of squared gradients.  Non-finite norm skips. */
 int mi355_sumsq_f32(const float* g, float* out, long long n, void* stream);
+/* *out += the sum of squares over n ranges in one launch: table (device, int64 pairs) = address of fp32 values, count.
+ * A NEGATIVE count marks |count| values that are partial sums already (added as they are): the slots that
+ * mi355_wgrad_job_fill's sumsq_slots names. */
+int mi355_sumsq_ranges(const long long* table, int n, float* out, void* stream);
 int mi355_zero_f32(float* p, long long n, void* stream);
 /* Zero n ranges in one launch: table (device, int64 pairs) = address (16-byte aligned), bytes (multiple of 16). */
 int mi355_zero_ranges(const long long* table, int n, void* stream);

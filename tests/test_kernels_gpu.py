@@ -333,6 +333,42 @@ def test_mse_and_schedule_ops():
     close(o, ops_ref.ddim_step(e, tt, x, acp, 50), 2e-5, 2e-5, "ddim step")
 
 
+def test_sumsq_ranges_and_wgrad_job_slots():
+    """mi355_sumsq_ranges: squares over aligned, unaligned, ragged and empty-tail ranges plus a range of ready partial
+    sums (negative count), against float64.  A single unsplit weight-gradient job with `sumsq_slots` leaves the sum of
+    squares of exactly the gradient it stored in the 64 slots; a pixel-split job leaves them untouched."""
+    import ctypes
+    from image_generator_amd.ops import lib, check, _stream, WgradQueue
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    buf = torch.randn(300_000, generator=g).to(d)
+    parts = torch.rand(64, generator=g).to(d)
+    spans = [(0, 100_000), (100_001, 37), (100_040, 3), (150_003, 149_997)]
+    rows = [(buf.data_ptr() + 4 * o, n) for o, n in spans] + [(parts.data_ptr(), -64)]
+    table = torch.tensor(rows, dtype=torch.int64).to(d)
+    out = torch.full((1,), 2.0, device=d)
+    check(lib.mi355_sumsq_ranges(table.data_ptr(), len(rows), out.data_ptr(), _stream()))
+    want = 2.0 + sum(float(buf[o:o + n].double().pow(2).sum()) for o, n in spans) + float(parts.double().sum())
+    assert abs(float(out) - want) <= 1e-5 * want, (float(out), want)
+
+    for B, H, split in ((2, 8, False), (16, 64, True)):
+        C, Co = 32, 48
+        x = torch.randn(B, H, H, C, generator=g).to(d).to(BF)
+        dy = torch.randn(B, H, H, Co, generator=g).to(d).to(BF)
+        dw = torch.zeros(Co, 9, C, device=d)
+        slots = torch.zeros(64, device=d)
+        q = WgradQueue(d)
+        q.zero_split_outputs = True
+        q.track_sumsq(slots, dw.data_ptr(), dw.data_ptr() + 4 * dw.numel())
+        q.push(dy, x, dw, None, B, H, H, C, Co, 3, 1, False, H, H)
+        q.join()
+        torch.cuda.synchronize()
+        assert (len(q.covered) == 0) == split, (B, H, q.covered)
+        want = 0.0 if split else float(dw.double().pow(2).sum())
+        assert float(dw.abs().max()) > 0
+        assert abs(float(slots.double().sum()) - want) <= 1e-5 * max(want, 1.0), (split, float(slots.sum()), want)
+
+
 def test_adamw_matches_torch():
     from image_generator_amd.ops import lib, check, _stream
     d = dev()
