@@ -29,6 +29,7 @@ struct WgradArgs {
     int nmain;          // LDS-DMA launch: number of workgroups that have work (a grouped launch pads each job)
     float* sumsq;       // optional 64 fp32 slots: unsplit jobs add the sum of squares of what they store (the global
                         // gradient norm then needs no second pass over these gradients)
+    bf16_t* dw16;       // optional: unsplit jobs store bf16 here (same [Cout][taps][Cin] layout) INSTEAD of fp32 into dw
 };
 
 constexpr int WG_BT = 160;          // channels per tile side
@@ -469,9 +470,13 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int blo
                 const int co = co0 + wm0 + i * 16 + g * 4 + r;
                 const int ci = ci0 + wn0 + j * 16 + li;
                 if (co < p.Cout && ci < p.Cin) {
-                    float* dst = p.dw + (size_t)co * ktot + (size_t)tap * p.Cin + ci;
-                    if (p.use_atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
-                    else { *dst = acc[i][j][r]; sq += acc[i][j][r] * acc[i][j][r]; }
+                    const size_t idx = (size_t)co * ktot + (size_t)tap * p.Cin + ci;
+                    if (p.use_atomic) unsafeAtomicAdd(p.dw + idx, acc[i][j][r]);
+                    else {
+                        if (p.dw16 != nullptr) p.dw16[idx] = f2bf(acc[i][j][r]);
+                        else p.dw[idx] = acc[i][j][r];
+                        sq += acc[i][j][r] * acc[i][j][r];
+                    }
                 }
             }
     if (p.sumsq != nullptr && !p.use_atomic) {
@@ -615,7 +620,7 @@ int mi355_wgrad_job_bytes(void) { return (int)sizeof(WgradJob); }
 // number of blocks the job occupies in the grouped launch (a multiple of 8), or a negative error.
 int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W,
                          int Cin, int Cout, int ksize, int stride, int ups, int Ho, int Wo, int first_block,
-                         int* splits_out, float* sumsq_slots) {
+                         int* splits_out, float* sumsq_slots, void* dw_bf16) {
     if (!host_job || !dy || !x || !dw) return mi355_fail(MI355_ERR_ARG, "wgrad_job_fill: null pointer");
     if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "wgrad_job_fill: ksize %d", ksize);
     if ((Cin & 7) || (Cout & 7)) return mi355_fail(MI355_ERR_ARG, "wgrad_job_fill: channels must be multiples of 8");
@@ -635,6 +640,7 @@ int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* d
     }
     a.use_atomic = a.splits > 1 ? 1 : 0;
     a.sumsq = a.use_atomic ? nullptr : sumsq_slots;
+    a.dw16 = a.use_atomic ? nullptr : (bf16_t*)dw_bf16;
     const int blocks = wgrad_dma_blocks(a);
     j->first_block = first_block;
     j->nblocks = (blocks + 7) & ~7;

@@ -169,24 +169,36 @@ class WgradQueue:
         # flush) when `zero_split_outputs` is set, so the owner need not clear the whole gradient buffer every step
         self.zero_split_outputs = False
         self._zero = []
-        # `track_sumsq(slots, lo, hi)`: unsplit jobs whose destination lies in [lo, hi) add the sum of squares of what they
-        # store to `slots` (64 floats) and are listed in `covered` (address, floats) for the owner of the gradient norm
-        self._sq_slots, self._sq_lo, self._sq_hi = None, 0, 0
+        # `track_unsplit(lo, hi, ...)`: jobs that are not pixel-split and whose destination lies in the address range
+        # [lo, hi) of an fp32 gradient buffer are listed in `covered` (address, floats) and
+        #   slots   - add the sum of squares of what they store to these 64 floats (the owner of the gradient norm then
+        #             skips their part of the buffer), and / or
+        #   stage16 - store bf16 into the buffer of that address laid out like [lo, hi) INSTEAD of fp32 (the staging
+        #             buffer of a bf16 gradient all-reduce: no separate pack pass over these gradients)
+        self._tr_lo = self._tr_hi = 0
+        self._tr_slots = self._tr_stage = None
         self.covered = []
+        self.covered_map = {}       # address -> floats, the same records
 
-    def track_sumsq(self, slots, lo=0, hi=0):
-        self._sq_slots, self._sq_lo, self._sq_hi = (None if slots is None else slots.data_ptr()), lo, hi
+    def track_unsplit(self, lo=0, hi=0, slots=None, stage16=None):
+        self._tr_lo, self._tr_hi = lo, hi
+        self._tr_slots = None if slots is None else slots.data_ptr()
+        self._tr_stage = None if stage16 is None else stage16.data_ptr()
         self.covered = []
+        self.covered_map = {}
 
     def push(self, dy, x, dw, dbias, B, H, W, cin, cout, ksize, stride, ups, Ho, Wo, callback=None):
         dwp = dw.data_ptr()
-        slots = self._sq_slots if (self._sq_slots is not None and self._sq_lo <= dwp < self._sq_hi) else None
+        tracked = self._tr_lo <= dwp < self._tr_hi
+        slots = self._tr_slots if tracked else None
+        dw16 = self._tr_stage + (dwp - self._tr_lo) // 2 if (tracked and self._tr_stage is not None) else None
         nb = lib.mi355_wgrad_job_fill(self._host.data_ptr() + self._n * self.jb, dy.data_ptr(), x.data_ptr(),
                                       dwp, _ptr(dbias), B, H, W, cin, cout, ksize, stride, int(ups), Ho, Wo,
-                                      self._blocks, ctypes.byref(self._splits), slots)
+                                      self._blocks, ctypes.byref(self._splits), slots, dw16)
         check(min(nb, 0), "wgrad_job_fill")
-        if slots is not None and self._splits.value == 1:
+        if tracked and self._splits.value == 1:
             self.covered.append((dwp, cout * ksize * ksize * cin))
+            self.covered_map[dwp] = cout * ksize * ksize * cin
         if self.zero_split_outputs and self._splits.value > 1:
             self._zero.append((dw.data_ptr(), dw.numel() * 4))
         self._n += 1

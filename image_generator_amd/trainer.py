@@ -66,14 +66,21 @@ class GradBucketReducer:
         # bucket boundaries over [0, n_big) aligned to weight boundaries, then one tail bucket
         packs = sorted(grad_packs, key=lambda t: t[0])
         self.buckets = []      # (start, end, [packs])
-        cur_start, cur_packs = 0, []
+        self._layers = []      # per bucket: (offset, numel) of its layers, ascending
+        cur_start, cur_packs, cur_layers = 0, [], []
         for o, n, pk in packs:
             cur_packs.append(pk)
+            cur_layers.append((o, n))
             if o + n - cur_start >= bucket_elems:
                 self.buckets.append([cur_start, o + n, cur_packs])
-                cur_start, cur_packs = o + n, []
+                self._layers.append(cur_layers)
+                cur_start, cur_packs, cur_layers = o + n, [], []
         if cur_packs or cur_start < n_big:
             self.buckets.append([cur_start, n_big, cur_packs])
+            self._layers.append(cur_layers)
+        # address -> floats of the gradients that their producer already stored as bf16 into `stage_all` (a
+        # `WgradQueue.covered_map` whose jobs were given the staging buffer): the pack pass skips them
+        self.staged = None
         self.tail = (n_big, self.flat_grad.numel())
         self.active = self.world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1"
         self._counts = []
@@ -89,14 +96,28 @@ class GradBucketReducer:
     def reset(self):
         self._counts = [len(pks) for _, _, pks in self.buckets]
 
-    def _launch(self, start, end, stage):
+    def _pack(self, start, end, layers):
+        """fp32 -> bf16 into the staging buffer, over [start, end) minus the layers whose gradients are staged already."""
+        g, st, staged = self.flat_grad, self.stage_all, self.staged
+        cur = start
+        if staged:
+            base = g.data_ptr()
+            for o, n in layers:
+                if staged.get(base + 4 * o) == n:
+                    if o > cur:
+                        st[cur:o].copy_(g[cur:o])
+                    cur = o + n
+        if cur < end:
+            st[cur:end].copy_(g[cur:end])
+
+    def _launch(self, start, end, stage, layers=()):
         g = self.flat_grad[start:end]
         if self.use_cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                stage.copy_(g)                                   # fp32 -> bf16 pack
+                self._pack(start, end, layers)
                 dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
                 if self.unpack:
                     g.copy_(stage)                               # back to fp32 (the optimizer divides by world)
@@ -110,7 +131,7 @@ class GradBucketReducer:
         self._counts[b] -= 1
         if self._counts[b] == 0 and self.active:
             s, e, _ = self.buckets[b]
-            self._launch(s, e, self._stage[b])
+            self._launch(s, e, self._stage[b], self._layers[b])
 
     def finish(self):
         """Call after backward: flush buckets that never fired, reduce the tail, join the streams."""
@@ -118,7 +139,7 @@ class GradBucketReducer:
             for b, c in enumerate(self._counts):
                 if c > 0:
                     s, e, _ = self.buckets[b]
-                    self._launch(s, e, self._stage[b])
+                    self._launch(s, e, self._stage[b], self._layers[b])
             if self.tail[1] > self.tail[0]:
                 self._launch(self.tail[0], self.tail[1], self._tail_stage)
             if self.use_cuda:
@@ -309,6 +330,12 @@ class DenoiserTrainer:
         self._fused_sumsq = (self.wgrad_queue is not None and self.reducer is None and not self.opt.frozen_base
                              and os.environ.get("MI355_NO_FUSED_SUMSQ") != "1")
         self._covered = None
+        # data-parallel full fine-tune: unsplit weight-gradient jobs store bf16 straight into the reducer's staging
+        # buffer, so the fp32 -> bf16 pack pass touches only what is left (the fp32 buffer and `param.grad` do not
+        # hold those gradients then)
+        self._direct_stage = (self.wgrad_queue is not None and self.reducer is not None and self.reducer.active
+                              and self.reducer.use_cuda and not self.reducer.unpack and not self.opt.frozen_base
+                              and os.environ.get("MI355_NO_DIRECT_STAGE") != "1")
 
     def forward_backward(self, latents, noise, t, ctx):
         B = latents.shape[0]
@@ -322,7 +349,12 @@ class DenoiserTrainer:
         if fused:
             g = self.opt.grad
             check(lib.mi355_zero_f32(self.opt.sq_slots.data_ptr(), 64, _stream()), "zero")
-            self.wgrad_queue.track_sumsq(self.opt.sq_slots, g.data_ptr(), g.data_ptr() + 4 * g.numel())
+            self.wgrad_queue.track_unsplit(g.data_ptr(), g.data_ptr() + 4 * g.numel(), slots=self.opt.sq_slots)
+        staged = self._direct_stage and self.wgrad_queue is not None
+        if staged:
+            g = self.opt.grad
+            self.wgrad_queue.track_unsplit(g.data_ptr(), g.data_ptr() + 4 * g.numel(), stage16=self.reducer.stage_all)
+            self.reducer.staged = self.wgrad_queue.covered_map
         pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
         loss = mse_loss(pred, noise)
         self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched
@@ -336,12 +368,15 @@ class DenoiserTrainer:
                 self.reduce_queue.flush()
         finally:
             if fused:
-                self.wgrad_queue.track_sumsq(None)
+                self.wgrad_queue.track_unsplit()
             self._ops.set_wgrad_queue(None)
             self._ops.set_reduce_queue(None)
         self.unet.finish_grads()
         if self.reducer is not None:
             self.reducer.finish()
+            self.reducer.staged = None
+        if staged:
+            self.wgrad_queue.track_unsplit()
         return loss.detach()
 
     def train_step(self, latents, noise, t, ctx, epoch_float=None):

@@ -359,7 +359,7 @@ def test_sumsq_ranges_and_wgrad_job_slots():
         slots = torch.zeros(64, device=d)
         q = WgradQueue(d)
         q.zero_split_outputs = True
-        q.track_sumsq(slots, dw.data_ptr(), dw.data_ptr() + 4 * dw.numel())
+        q.track_unsplit(dw.data_ptr(), dw.data_ptr() + 4 * dw.numel(), slots=slots)
         q.push(dy, x, dw, None, B, H, H, C, Co, 3, 1, False, H, H)
         q.join()
         torch.cuda.synchronize()
@@ -367,6 +367,21 @@ def test_sumsq_ranges_and_wgrad_job_slots():
         want = 0.0 if split else float(dw.double().pow(2).sum())
         assert float(dw.abs().max()) > 0
         assert abs(float(slots.double().sum()) - want) <= 1e-5 * max(want, 1.0), (split, float(slots.sum()), want)
+        # the same job with a bf16 destination: unsplit -> bf16 there (round to nearest even) and dw untouched;
+        # split -> the bf16 buffer untouched, fp32 accumulated into dw as before
+        dw2 = torch.zeros_like(dw)
+        st16 = torch.full((Co, 9, C), 7.0, dtype=BF, device=d)
+        q.track_unsplit(dw2.data_ptr(), dw2.data_ptr() + 4 * dw2.numel(), stage16=st16)
+        q.push(dy, x, dw2, None, B, H, H, C, Co, 3, 1, False, H, H)
+        q.join()
+        torch.cuda.synchronize()
+        if split:
+            assert float((st16.float() - 7.0).abs().max()) == 0 and q.covered_map == {}
+            close(dw2, dw, 1e-4, 1e-4 * float(dw.abs().max()), "split wgrad with bf16 destination")
+        else:
+            assert q.covered_map == {dw2.data_ptr(): dw2.numel()}
+            assert float(dw2.abs().max()) == 0
+            assert torch.equal(st16, dw.to(BF))
 
 
 def test_adamw_matches_torch():
