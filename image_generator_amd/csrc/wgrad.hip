@@ -27,11 +27,12 @@ struct WgradArgs {
     unsigned dy_bytes, x_bytes;   // extents of dy / x for the LDS-DMA loader's buffer descriptors (< 2 GiB)
     int lw, lh;         // log2(Wo), log2(Ho) when both are powers of two, else -1
     int nmain;          // LDS-DMA launch: number of workgroups that have work (a grouped launch pads each job)
-    float* sumsq;       // optional 64 fp32 slots: unsplit jobs add the sum of squares of what they store (the global
+    float* sumsq;       // optional WG_SQ_SLOTS fp32 slots: unsplit jobs add the sum of squares of what they store (the global
                         // gradient norm then needs no second pass over these gradients)
     bf16_t* dw16;       // optional: unsplit jobs store bf16 here (same [Cout][taps][Cin] layout) INSTEAD of fp32 into dw
 };
 
+constexpr int WG_SQ_SLOTS = 1024;   // partial sums of squares are spread over this many addresses (atomics to one address serialise)
 constexpr int WG_BT = 160;          // channels per tile side
 constexpr int WG_BK = 64;           // pixels per k tile
 constexpr int WG_LD = 352;          // LDS row stride in bytes
@@ -481,7 +482,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int blo
             }
     if (p.sumsq != nullptr && !p.use_atomic) {
         sq = wave_sum(sq);
-        if (lane == 0) atomicAdd(p.sumsq + ((block_id * 4 + wave) & 63), sq);
+        if (lane == 0) atomicAdd(p.sumsq + ((block_id * 4 + wave) & (WG_SQ_SLOTS - 1)), sq);
     }
 #endif
 }
@@ -614,6 +615,7 @@ static int wgrad_dma_blocks(WgradArgs& a) {
 }
 
 int mi355_wgrad_job_bytes(void) { return (int)sizeof(WgradJob); }
+int mi355_wgrad_sumsq_slots(void) { return WG_SQ_SLOTS; }
 
 // Fills one job record in HOST memory (mi355_wgrad_job_bytes() bytes).  dw (and dbias) must have been
 // zeroed by the caller when the job is split (the record says so through *splits_out).  Returns the

@@ -171,7 +171,7 @@ class WgradQueue:
         self._zero = []
         # `track_unsplit(lo, hi, ...)`: jobs that are not pixel-split and whose destination lies in the address range
         # [lo, hi) of an fp32 gradient buffer are listed in `covered` (address, floats) and
-        #   slots   - add the sum of squares of what they store to these 64 floats (the owner of the gradient norm then
+        #   slots   - add the sum of squares of what they store to these `mi355_wgrad_sumsq_slots()` floats (the owner of the gradient norm then
         #             skips their part of the buffer), and / or
         #   stage16 - store bf16 into the buffer of that address laid out like [lo, hi) INSTEAD of fp32 (the staging
         #             buffer of a bf16 gradient all-reduce: no separate pack pass over these gradients)

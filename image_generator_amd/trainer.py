@@ -168,8 +168,8 @@ class FusedAdamW:
         dev = self.flat.device
         self.hyper = torch.zeros(9, dtype=F32, device=dev)
         self.state = torch.zeros(2, dtype=F32, device=dev)
-        # 64 partial sums of squares that unsplit weight-gradient jobs add to while they store their results
-        self.sq_slots = torch.zeros(64, dtype=F32, device=dev)
+        # partial sums of squares that unsplit weight-gradient jobs add to while they store their results
+        self.sq_slots = torch.zeros(int(lib.mi355_wgrad_sumsq_slots()), dtype=F32, device=dev)
         self._sq_tables = {}
         self._hyper_ring = [torch.zeros(9, dtype=F32).pin_memory() for _ in range(8)]
 
@@ -348,7 +348,7 @@ class DenoiserTrainer:
         self._covered = None
         if fused:
             g = self.opt.grad
-            check(lib.mi355_zero_f32(self.opt.sq_slots.data_ptr(), 64, _stream()), "zero")
+            check(lib.mi355_zero_f32(self.opt.sq_slots.data_ptr(), self.opt.sq_slots.numel(), _stream()), "zero")
             self.wgrad_queue.track_unsplit(g.data_ptr(), g.data_ptr() + 4 * g.numel(), slots=self.opt.sq_slots)
         staged = self._direct_stage and self.wgrad_queue is not None
         if staged:

@@ -107,13 +107,14 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
 /* Deferred, batched weight gradients: fill job records on the host, copy them to the device, launch once.
  * mi355_wgrad_job_fill returns the job's block count (multiple of 8); first_block = running sum of them.
  * dw/dbias of every job must be zero before the launch (split jobs and bias sums accumulate atomically).
- * sumsq_slots (optional, 64 device floats, zeroed by the caller): a job that is NOT pixel-split (*splits_out == 1)
+ * sumsq_slots (optional, mi355_wgrad_sumsq_slots() device floats, zeroed by the caller): a job that is NOT pixel-split (*splits_out == 1)
  * adds the sum of squares of the dw it stores to these slots, so the global gradient norm of the optimizer
  * (trainer.py:257) needs no second pass over that gradient; split jobs ignore it.
  * dw_bf16 (optional, same [Cout][k*k][Cin] layout in bf16): a job that is not pixel-split stores its result there,
  * rounded to nearest even, INSTEAD of fp32 into dw (the staging buffer of a bf16 gradient all-reduce); split jobs
  * ignore it and accumulate into dw. */
 int mi355_wgrad_job_bytes(void);
+int mi355_wgrad_sumsq_slots(void);
 int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W,
                          int Cin, int Cout, int ksize, int stride, int ups, int Ho, int Wo, int first_block,
                          int* splits_out, float* sumsq_slots, void* dw_bf16);

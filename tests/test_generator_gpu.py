@@ -298,7 +298,7 @@ def test_gradient_norm_from_weight_gradient_launches_matches_full_pass():
         assert cov and sum(n for _, n in cov) > 0.5 * tr.opt.grad.numel()      # most of the buffer is never re-read
         table, rows = tr.opt._uncovered_table(cov)
         assert sum(n for _, n in cov) + int(table[:rows - 1, 1].sum()) == tr.opt.grad.numel()
-        assert int(table[rows - 1, 1]) == -64
+        assert int(table[rows - 1, 1]) == -tr.opt.sq_slots.numel()
 
 
 def test_deferred_grouped_wgrad_matches_immediate():

@@ -336,7 +336,7 @@ def test_mse_and_schedule_ops():
 def test_sumsq_ranges_and_wgrad_job_slots():
     """mi355_sumsq_ranges: squares over aligned, unaligned, ragged and empty-tail ranges plus a range of ready partial
     sums (negative count), against float64.  A single unsplit weight-gradient job with `sumsq_slots` leaves the sum of
-    squares of exactly the gradient it stored in the 64 slots; a pixel-split job leaves them untouched."""
+    squares of exactly the gradient it stored in the slots; a pixel-split job leaves them untouched."""
     import ctypes
     from image_generator_amd.ops import lib, check, _stream, WgradQueue
     d = dev()
@@ -356,7 +356,7 @@ def test_sumsq_ranges_and_wgrad_job_slots():
         x = torch.randn(B, H, H, C, generator=g).to(d).to(BF)
         dy = torch.randn(B, H, H, Co, generator=g).to(d).to(BF)
         dw = torch.zeros(Co, 9, C, device=d)
-        slots = torch.zeros(64, device=d)
+        slots = torch.zeros(int(lib.mi355_wgrad_sumsq_slots()), device=d)
         q = WgradQueue(d)
         q.zero_split_outputs = True
         q.track_unsplit(dw.data_ptr(), dw.data_ptr() + 4 * dw.numel(), slots=slots)
