@@ -114,6 +114,11 @@ class ImageGenerator(nn.Module):
             eps = self.unet(x2, t_dev, encoder_hidden_states=emb_pair).sample
             lat.copy_(sch.step_cfg(eps, lat, coef_dev))
 
+        from .unet import context_kv_cache
+        with context_kv_cache():            # keys / values of the text states: projected in the first step only
+            return self._sampling_loop(sch, one_step, lat, emb_pair, t_dev, coef_dev, host, guidance_scale, n, use_graph)
+
+    def _sampling_loop(self, sch, one_step, lat, emb_pair, t_dev, coef_dev, host, guidance_scale, n, use_graph):
         graph = None
         for i, t in enumerate(sch.timesteps):
             a_t, a_p, g = sch.coefficients(t, guidance_scale)

@@ -19,6 +19,7 @@ Design (MI355X-first, not a module-by-module translation):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Sequence
 
@@ -171,6 +172,23 @@ class ResnetBlock(nn.Module):
         return self.conv2(h, residual=res)
 
 
+class context_kv_cache:
+    """`with context_kv_cache():` - inside, under no_grad, every cross-attention layer projects its text states to keys
+    and values ONCE and re-uses them: the text states of a sampling loop are the same in all of its steps
+    (image_generator.py:76-78,93-95), so 16 GEMMs per step become 16 per image batch.  The caller promises that
+    `encoder_hidden_states` and the weights do not change inside the block."""
+    active = None
+
+    def __enter__(self):
+        self._prev = context_kv_cache.active
+        context_kv_cache.active = {} if os.environ.get("MI355_NO_KV_CACHE") != "1" else None
+        return self
+
+    def __exit__(self, *exc):
+        context_kv_cache.active = self._prev
+        return False
+
+
 class Attention(nn.Module):
     def __init__(self, query_dim, heads, context_dim=None):
         super().__init__()
@@ -196,8 +214,16 @@ class Attention(nn.Module):
         if self._plain() and self.fused_pack.w16 is not None:
             if self.is_cross:
                 q = self.to_q(x)
-                kv = LinearFn.apply(context, self.fused_pack, None, None, False, self.to_k.weight, self.to_v.weight)
-                a = AttentionFn.apply(q, kv, None, self.heads)
+                cache = context_kv_cache.active if not torch.is_grad_enabled() else None
+                kv = None if cache is None else cache.get(id(self))
+                if kv is not None and (kv[0] is not context or kv[1].shape[:2] != context.shape[:2]):
+                    kv = None
+                if kv is None:
+                    kv = (context, LinearFn.apply(context, self.fused_pack, None, None, False, self.to_k.weight,
+                                                  self.to_v.weight))
+                    if cache is not None:
+                        cache[id(self)] = kv
+                a = AttentionFn.apply(q, kv[1], None, self.heads)
             else:
                 qkv = LinearFn.apply(x, self.fused_pack, None, None, False, self.to_q.weight, self.to_k.weight,
                                      self.to_v.weight)

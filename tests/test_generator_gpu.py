@@ -88,6 +88,26 @@ def test_sampler_matches_oracle_and_graph_matches_eager():
     eager = gen.sample_latents(emb, lat0, 4, 7.5, use_graph=False)
     graphed = gen.sample_latents(emb, lat0, 4, 7.5, use_graph=True)
     assert torch.equal(eager, graphed)
+    # the loop projects the text states to keys / values once (first step) and re-uses them: same result, bit for bit,
+    # as projecting them in every step; outside the loop nothing stays cached
+    import os
+    from image_generator_amd.unet import context_kv_cache
+    assert context_kv_cache.active is None
+    os.environ["MI355_NO_KV_CACHE"] = "1"
+    try:
+        uncached = gen.sample_latents(emb, lat0, 4, 7.5, use_graph=False)
+    finally:
+        os.environ.pop("MI355_NO_KV_CACHE")
+    assert torch.equal(eager, uncached)
+    with context_kv_cache(), torch.no_grad():
+        x2, t2 = torch.cat([lat0, lat0]), torch.full((4,), 500.0, device=D)
+        a = gen.unet(x2, t2, encoder_hidden_states=emb).sample
+        n_cross = sum(1 for m in gen.unet.modules() if getattr(m, "is_cross", False))
+        assert len(context_kv_cache.active) == n_cross > 0
+        emb2 = emb.flip(0).contiguous()                       # other text states: the cached projections are not used
+        b = gen.unet(x2, t2, encoder_hidden_states=emb2).sample
+    with torch.no_grad():
+        assert torch.equal(b, gen.unet(x2, t2, encoder_hidden_states=emb2).sample) and not torch.equal(a, b)
     ref = _oracle_of(gen)
     acp = ops_ref.sd_alphas_cumprod()
     x = lat0.cpu()
