@@ -4,7 +4,7 @@ WRITE_SIZE is taken as reported.  Both are in KiB.  usage: pmc_step_traffic.py <
 import csv, glob, json, sys, collections
 
 FAMS = [("gemm_conv", ("gemm_dma_kernel", "gemm_wide_kernel", "gemm_kernel", "splitk_reduce_kernel", "gemm_skinny_kernel")),
-        ("wgrad", ("wgrad_",)), ("attention", ("attn_",)), ("adamw", ("adamw_kernel", "sumsq_kernel")),
+        ("wgrad", ("wgrad_",)), ("attention", ("attn_",)), ("adamw", ("adamw_kernel", "sumsq_")),
         ("norm", ("gn_", "ln_", "reduce_rows")), ]
 
 
