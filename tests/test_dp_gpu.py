@@ -76,3 +76,61 @@ def test_dp_step_with_reducer_matches_plain_step():
     for a, b in zip(na, nb):
         assert math.isfinite(a) and abs(a - b) <= 2e-2 * b, (na, nb)
     assert la[-1] < la[0]
+
+
+def test_lora_dp_step_with_reducer_matches_plain_step():
+    """LoRA fine-tune with the gradient reducer on (one rank over RCCL): the adapters are the reducer's only (tail)
+    bucket, the frozen base has none, and the optimizer consumes the staged bf16 adapter gradients - the trajectory
+    stays with the plain LoRA step's (bf16 rounding of the gradients only) and the base weights never move."""
+    from image_generator_amd.generator import inject_lora
+    from image_generator_amd.trainer import DenoiserTrainer
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    g = torch.Generator().manual_seed(23)
+    lat, noise = torch.randn(4, 4, 8, 8, generator=g).to(D), torch.randn(4, 4, 8, 8, generator=g).to(D)
+    ts, ctx = torch.randint(0, 1000, (4,), generator=g).to(D), torch.randn(4, 16, 64, generator=g).to(D).to(torch.bfloat16)
+
+    def run(with_reducer):
+        torch.manual_seed(0)
+        unet = UNet2DConditionModel(DenoiserConfig.small())
+        adapters = inject_lora(unet, r=4, alpha=0.5)
+        with torch.no_grad():
+            for ad in adapters:
+                ad.lora_B.weight.normal_(0, 0.05)
+        unet.to(D)
+        base = {n: p.detach().clone() for n, p in unet.named_parameters() if not p.requires_grad}
+        if with_reducer:
+            os.environ["MI355_FORCE_REDUCER"] = "1"
+        try:
+            tr = DenoiserTrainer(unet, lr=1e-3)
+        finally:
+            os.environ.pop("MI355_FORCE_REDUCER", None)
+        assert tr.opt.frozen_base and (tr.reducer is not None) == with_reducer
+        if with_reducer:
+            assert tr.reducer.active and not tr._direct_stage and tr.reducer.tail[1] - tr.reducer.tail[0] == tr.opt.grad.numel()
+        losses, norms = [], []
+        for _ in range(4):
+            losses.append(float(tr.train_step(lat, noise, ts, ctx)))
+            norms.append(tr.opt.grad_norm())
+        for n, p in unet.named_parameters():
+            if not p.requires_grad:
+                assert torch.equal(p.detach(), base[n]), n
+        return losses, norms, tr
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(D))
+    try:
+        la, na, tr = run(True)
+        st, fg = tr.reducer.stage_all.float(), tr.opt.grad
+        assert float(fg.norm()) > 0 and float((st - fg).norm() / fg.norm()) <= 2 ** -8
+    finally:
+        dist.destroy_process_group()
+    lb, nb, _ = run(False)
+    assert la[0] == lb[0]
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 1e-2 * abs(b), (la, lb)
+    for a, b in zip(na, nb):
+        assert math.isfinite(a) and a > 0 and abs(a - b) <= 2e-2 * b, (na, nb)
+    assert la[-1] < la[0]
