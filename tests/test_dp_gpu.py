@@ -134,3 +134,65 @@ def test_lora_dp_step_with_reducer_matches_plain_step():
     for a, b in zip(na, nb):
         assert math.isfinite(a) and a > 0 and abs(a - b) <= 2e-2 * b, (na, nb)
     assert la[-1] < la[0]
+
+
+def test_fullsize_direct_staging_matches_pack_pass():
+    """SD-v1 denoiser at the benchmark size (batch 32, 32x32 latents) with the reducer on: the level-0 weight gradients
+    are pixel-split there (fp32 atomics, packed afterwards), everything else is stored as bf16 by its own job.  The
+    staged buffer equals, to bf16 rounding, the fp32 gradients of the same backward pass without direct staging, every
+    range of the flat buffer is either staged by a job or packed, and both kinds occur."""
+    from image_generator_amd.trainer import DenoiserTrainer
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    torch.manual_seed(98)
+    with torch.device(D):
+        unet = UNet2DConditionModel(DenoiserConfig.sd_v1())
+    B, L, T = 32, 32, 77
+    g = torch.Generator(device=D).manual_seed(8)
+    lat = torch.randn(B, 4, L, L, device=D, generator=g) * 0.9
+    noise = torch.randn(B, 4, L, L, device=D, generator=g)
+    ctx = torch.randn(B, T, 768, device=D, generator=g).to(torch.bfloat16)
+    ts = torch.randint(0, 1000, (B,), device=D, generator=g)
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(D))
+    try:
+        out = []
+        for direct in (True, False):
+            os.environ["MI355_FORCE_REDUCER"] = "1"
+            if not direct:
+                os.environ["MI355_NO_DIRECT_STAGE"] = "1"
+            try:
+                tr = DenoiserTrainer(unet, lr=1e-4)
+            finally:
+                os.environ.pop("MI355_FORCE_REDUCER", None)
+                os.environ.pop("MI355_NO_DIRECT_STAGE", None)
+            assert tr._direct_stage == direct
+            tr.opt.grad.zero_()
+            tr.reducer.stage_all.fill_(float("nan"))            # every element must be written by a job or by the pack pass
+            staged = {}
+            if direct:
+                keep = tr.reducer.finish
+
+                def finish(keep=keep, tr=tr, staged=staged):
+                    staged.update(tr.reducer.staged or {})
+                    keep()
+                tr.reducer.finish = finish
+            tr.forward_backward(lat, noise, ts, ctx)
+            torch.cuda.synchronize()
+            out.append((tr.reducer.stage_all.float().clone(), tr.opt.grad.clone(), staged))
+            n_layers = sum(len(l) for l in tr.reducer._layers)
+            del tr
+        (st_d, fg_d, staged), (st_p, fg_p, _) = out
+        assert bool(torch.isfinite(st_d).all()) and bool(torch.isfinite(st_p).all())
+        assert 0 < len(staged) < n_layers                          # unsplit jobs staged, pixel-split ones packed
+        covered = sum(staged.values())
+        assert 0.8 * st_d.numel() < covered < st_d.numel()
+        assert float((st_p - fg_p).norm() / fg_p.norm()) <= 2 ** -8
+        assert float((st_d - fg_p).norm() / fg_p.norm()) <= 2 ** -8
+        # the fp32 buffer of the direct run holds only what no job staged
+        assert float(fg_d.norm()) < float(fg_p.norm())
+    finally:
+        dist.destroy_process_group()
