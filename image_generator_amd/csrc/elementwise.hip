@@ -333,6 +333,28 @@ __global__ __launch_bounds__(256) void sumsq_bf16_kernel(const bf16_t* __restric
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
+// The same sum with a result that depends only on the data: every block stores its partial, one block adds the partials
+// in index order.  Data-parallel replicas compute their clip factor from identical reduced gradients; with the atomic
+// version the order of the additions differs from rank to rank, the factors differ in the last bit and the replicas'
+// weights drift apart by an ulp per step.
+__global__ __launch_bounds__(256) void sumsq_bf16_partial_kernel(const bf16_t* __restrict__ g, float* __restrict__ partial, size_t n8) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *(const bf16x8*)(g + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[e] * (float)v[e];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] += s;
+}
 // hyper (device floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=bias_corr1 [6]=bias_corr2
 //                        [7]=max_grad_norm (<=0: no clipping) [8]=grad pre-scale (e.g. 1/world)
 // state (device floats): [0]=sum of squared grads (input) ; [1]=skip flag output (1 when non-finite)
@@ -833,6 +855,17 @@ int mi355_sumsq_bf16(const void* g, float* out, long long n, void* stream) {
     ProfScope prof(FAM_ELEM, ST, (double)n * 2);
     hipLaunchKernelGGL(sumsq_bf16_kernel, dim3(GRID_FOR(n / 8 + 1, 1024)), dim3(256), 0, ST, (const bf16_t*)g, out, (size_t)n / 8);
     return mi355_check_launch("sumsq_bf16");
+}
+int mi355_sumsq_bf16_ordered(const void* g, float* out, float* partials, int max_partials, long long n, void* stream) {
+    if (!g || !out || !partials || (n & 7)) return mi355_fail(MI355_ERR_ARG, "sumsq_bf16_ordered: null pointer or n not a multiple of 8");
+    if (((uintptr_t)g) & 15) return mi355_fail(MI355_ERR_ARG, "sumsq_bf16_ordered: buffer must be 16-byte aligned");
+    if (max_partials < 1) return mi355_fail(MI355_ERR_ARG, "sumsq_bf16_ordered: no room for partial sums");
+    ProfScope prof(FAM_ELEM, ST, (double)n * 2);
+    int grid = GRID_FOR(n / 8 + 1, 1024);
+    if (grid > max_partials) grid = max_partials;
+    hipLaunchKernelGGL(sumsq_bf16_partial_kernel, dim3(grid), dim3(256), 0, ST, (const bf16_t*)g, partials, (size_t)n / 8);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST, (const float*)partials, grid, out);
+    return mi355_check_launch("sumsq_bf16_ordered");
 }
 int mi355_zero_f32(float* p, long long n, void* stream) {
     if (!p) return mi355_fail(MI355_ERR_ARG, "zero: null pointer");

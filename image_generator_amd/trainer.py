@@ -229,7 +229,9 @@ class FusedAdamW:
             return
         if grad16 is not None and n % 8 == 0:
             assert grad16.numel() == n and grad16.dtype == BF16
-            check(lib.mi355_sumsq_bf16(grad16.data_ptr(), self.state.data_ptr(), n, s), "sumsq_bf16")
+            # fixed order of additions: every rank derives the same clip factor from the same reduced gradients
+            check(lib.mi355_sumsq_bf16_ordered(grad16.data_ptr(), self.state.data_ptr(), self.sq_slots.data_ptr(),
+                                               self.sq_slots.numel(), n, s), "sumsq_bf16_ordered")
             check(lib.mi355_adamw_step_g16(self.flat.data_ptr(), grad16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                            self.flat16.data_ptr(), self.hyper.data_ptr(), self.state.data_ptr(), n, s),
                   "adamw_g16")

@@ -214,6 +214,11 @@ int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16,
 /* The same two steps on bf16 gradients: a data-parallel step feeds the optimizer the all-reduced bf16 staging
  * buffer directly instead of unpacking it to fp32 first (n a multiple of 8 for the norm, of 4 for the update). */
 int mi355_sumsq_bf16(const void* g16, float* out, long long n, void* stream);
+/* The same sum in a fixed order of additions (per-block partials into `partials`, at most max_partials of them, then one
+ * block adds them by index): identical reduced gradients give bit-identical norms on every data-parallel rank, so the
+ * replicas apply the same clip factor and stay bit-identical (the atomic form above differs in the last bit from run
+ * to run). */
+int mi355_sumsq_bf16_ordered(const void* g16, float* out, float* partials, int max_partials, long long n, void* stream);
 int mi355_adamw_step_g16(float* p, const void* g16, float* m, float* v, void* p_bf16, const float* hyper,
                          const float* state, long long n, void* stream);
 
