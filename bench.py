@@ -30,8 +30,8 @@ FWD_GFLOP_PER_SAMPLE_256 = 180.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--latent", type=int, default=32, help="latent side (32 = 256x256 images)")
     ap.add_argument("--ctx-len", type=int, default=77)

@@ -866,7 +866,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (128 + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     const int grid = a.tiles_m * a.tiles_n * a.splitk;
@@ -881,7 +881,7 @@ static int launch_gemm_wide(const GemmArgs& a, unsigned a_bytes, unsigned b_byte
     static_assert(smem >= 2 * 26 * 1024, "stages must fit");
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_wide_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_wide_kernel<AMODE>), dim3(a.tiles_m * a.tiles_n), dim3(256), smem, s, a, a_bytes, b_bytes);
@@ -896,7 +896,7 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
     constexpr int smem = 2 * (128 + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     const int grid = a.tiles_m * a.tiles_n * a.splitk;
@@ -909,7 +909,7 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
         constexpr int smem3 = 3 * (128 + BN) * 128;
         static bool attr83_set = false;
         if (!attr83_set) {
-            hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+            (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
             attr83_set = true;
         }
         hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8, 128, 3>), dim3(grid), dim3(512), smem3, s, a, a_bytes, b_bytes);
@@ -918,7 +918,7 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
     if (grid <= nw8_max) {
         static bool attr8_set = false;
         if (!attr8_set) {
-            hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             attr8_set = true;
         }
         hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8>), dim3(grid), dim3(512), smem, s, a, a_bytes, b_bytes);

@@ -637,7 +637,7 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
         const size_t sh = ((size_t)(threads / 64) * 2 + 1) * C * sizeof(float);                                \
         static bool attr_set = false;                                                                          \
         if (!attr_set) {                                                                                       \
-            hipFuncSetAttribute((const void*)ln_bwd_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+            (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                 (int)(((size_t)(threads / 64) * 2 + 1) * 512 * NCH * sizeof(float)));          \
             attr_set = true;                                                                                   \
         }                                                                                                      \
