@@ -29,6 +29,7 @@ struct WgradArgs {
     int nmain;          // LDS-DMA launch: number of workgroups that have work (a grouped launch pads each job)
     float* sumsq;       // optional WG_SQ_SLOTS fp32 slots: unsplit jobs add the sum of squares of what they store (the global
                         // gradient norm then needs no second pass over these gradients)
+    int gci;            // block order: ci tiles are walked in groups of gci (see wgrad_dma_blocks)
     bf16_t* dw16;       // optional: unsplit jobs store bf16 here (same [Cout][taps][Cin] layout) INSTEAD of fp32 into dw
 };
 
@@ -251,9 +252,18 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int blo
     int lid = xcd_remap(block_id, grid_blocks);
     if (lid >= p.nmain) return;              // padding block of a grouped launch
     const int tap = lid % p.taps; lid /= p.taps;
-    const int tile_ci = lid % p.tiles_ci; lid /= p.tiles_ci;
-    const int tile_co = lid % p.tiles_co;
-    const int split = lid / p.tiles_co;
+    // inside one pixel split the (co, ci) tile plane is walked ci-group by ci-group (gci tiles wide), co tiles inside a
+    // group, ci tiles innermost: an XCD's contiguous chunk is then a near-square block of the plane and fetches
+    // (rows + columns) operand slices instead of (one row + every column)
+    const int plane = p.tiles_co * p.tiles_ci;
+    const int split = lid / plane;
+    const int t = lid - split * plane;
+    const int gsize = p.gci * p.tiles_co;
+    const int cg = t / gsize, r = t - cg * gsize;
+    int gw = p.tiles_ci - cg * p.gci;
+    if (gw > p.gci) gw = p.gci;
+    const int tile_co = r / gw;
+    const int tile_ci = cg * p.gci + (r - tile_co * gw);
     const int co0 = tile_co * WG_BT, ci0 = tile_ci * WG_BT;
     int ky = 0, kx = 0;
     if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
@@ -491,9 +501,14 @@ __device__ __forceinline__ void wgrad_dma_dispatch(const WgradArgs& p, const int
     const bool linear = p.stride == 1 && !p.ups;
     const int mode = (p.ksize == 1 && linear) ? 0 : (linear && p.lw >= 0) ? 1 : 2;
     bool bias = false;
-    if (p.dbias != nullptr) {                    // same decode as the body: tap fastest, then the ci tile
+    if (p.dbias != nullptr) {                    // same decode as the body: the workgroups of (tap 0, ci tile 0)
         const int lid = xcd_remap(block_id, grid_blocks);
-        bias = lid % p.taps == 0 && (lid / p.taps) % p.tiles_ci == 0;
+        const int t = (lid / p.taps) % (p.tiles_co * p.tiles_ci);
+        const int gsize = p.gci * p.tiles_co;
+        const int cg = t / gsize, r = t - cg * gsize;
+        int gw = p.tiles_ci - cg * p.gci;
+        if (gw > p.gci) gw = p.gci;
+        bias = lid % p.taps == 0 && cg == 0 && r % gw == 0;
     }
     if (bias) {
         if (mode == 0) wgrad_dma_body<0, true>(p, block_id, grid_blocks, smem);
@@ -611,6 +626,20 @@ static bool wgrad_dma_extents(WgradArgs& a) {
 }
 static int wgrad_dma_blocks(WgradArgs& a) {
     a.nmain = a.tiles_co * a.tiles_ci * a.taps * a.splits;
+    // An XCD runs a contiguous eighth of the block order: `per_xcd` tiles of the (co, ci) plane (all taps of a tile are
+    // adjacent).  When that is less than a plane, a block gci = sqrt(per_xcd) tiles wide reads the fewest operand slices
+    // through that XCD's L2; otherwise the XCD owns whole planes and reads each operand once anyway.
+    static const int force = getenv("MI355_WGRAD_GCI") ? atoi(getenv("MI355_WGRAD_GCI")) : -1;
+    const int plane = a.tiles_co * a.tiles_ci;
+    const int per_xcd = (plane * a.splits + 7) / 8;
+    int g = a.tiles_ci;
+    if (force > 0) g = force;
+    else if (force < 0 && per_xcd < plane) {
+        g = 1;
+        while ((g + 1) * (g + 1) <= per_xcd) ++g;       // floor(sqrt(per_xcd))
+        if (g * (g + 1) <= per_xcd) ++g;                // round to nearest
+    }
+    a.gci = g < 1 ? 1 : (g > a.tiles_ci ? a.tiles_ci : g);
     return a.nmain;
 }
 
@@ -698,8 +727,10 @@ int mi355_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, int
     if (a.splits > 1 && accumulate == 0) mi355_zero_async(dw, (size_t)Cout * a.taps * Cin * sizeof(float), st);
     if (dbias && accumulate == 0) mi355_zero_async(dbias, (size_t)Cout * sizeof(float), st);
     ProfScope prof(FAM_WGRAD, st, 2.0 * a.M * Cout * (double)a.taps * Cin);
-    if (dma)
-        hipLaunchKernelGGL(wgrad_dma_kernel, dim3(wgrad_dma_blocks(a)), dim3(256), 0, st, a);
+    if (dma) {
+        const int blocks = wgrad_dma_blocks(a);      // also completes `a` (block count, block order)
+        hipLaunchKernelGGL(wgrad_dma_kernel, dim3(blocks), dim3(256), 0, st, a);
+    }
     else
         hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * a.splits), dim3(256), 0, st, a);
     return mi355_check_launch("wgrad_kernel");
