@@ -80,8 +80,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // Hardware hands consecutive workgroup ids to the 8 XCDs in turn: with the plain (tile, head) grid and at most 8
+    // tiles per head, every tile of ONE head lands on a different L2 and each fetches that head's whole K / V (or
+    // Q / dO) again.  The remapped id gives an XCD a contiguous run of heads with all their tiles (attention of the
+    // train step 3.53 -> 3.37 ms).  With more tiles per head (4 096 tokens: 32) an XCD already runs several tiles of a
+    // head at once and the remapped order measured 0.7 % slower on the sampling step, so those grids keep the plain order.
+    int wg_x = blockIdx.x, wg_y = blockIdx.y;
+    if (gridDim.x <= 8) {
+        const int wg = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        wg_x = wg % gridDim.x; wg_y = wg / gridDim.x;
+    }
+    const int b = wg_y / p.H, h = wg_y % p.H;
+    const int q0 = wg_x * 128 + wave * 32;
     const bf16_t* Qb = p.q + (size_t)b * p.Nq * p.ldq + h * p.D;
     const bf16_t* Kb = p.k + (size_t)b * p.Nk * p.ldk + h * p.D;
     const bf16_t* Vb = p.v + (size_t)b * p.Nk * p.ldv + h * p.D;
@@ -229,8 +239,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int key = blockIdx.x * 128 + wave * 32 + l31;
+    // Hardware hands consecutive workgroup ids to the 8 XCDs in turn: with the plain (tile, head) grid and at most 8
+    // tiles per head, every tile of ONE head lands on a different L2 and each fetches that head's whole K / V (or
+    // Q / dO) again.  The remapped id gives an XCD a contiguous run of heads with all their tiles (attention of the
+    // train step 3.53 -> 3.37 ms).  With more tiles per head (4 096 tokens: 32) an XCD already runs several tiles of a
+    // head at once and the remapped order measured 0.7 % slower on the sampling step, so those grids keep the plain order.
+    int wg_x = blockIdx.x, wg_y = blockIdx.y;
+    if (gridDim.x <= 8) {
+        const int wg = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        wg_x = wg % gridDim.x; wg_y = wg / gridDim.x;
+    }
+    const int b = wg_y / p.H, h = wg_y % p.H;
+    const int key = wg_x * 128 + wave * 32 + l31;
     const bool k_ok = key < p.Nk;
     const bf16_t* Qb = p.q + (size_t)b * p.Nq * p.ldq + h * p.D;
     const bf16_t* Gb = p.dout + (size_t)b * p.Nq * p.ldo + h * p.D;
@@ -356,8 +376,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+    // Hardware hands consecutive workgroup ids to the 8 XCDs in turn: with the plain (tile, head) grid and at most 8
+    // tiles per head, every tile of ONE head lands on a different L2 and each fetches that head's whole K / V (or
+    // Q / dO) again.  The remapped id gives an XCD a contiguous run of heads with all their tiles (attention of the
+    // train step 3.53 -> 3.37 ms).  With more tiles per head (4 096 tokens: 32) an XCD already runs several tiles of a
+    // head at once and the remapped order measured 0.7 % slower on the sampling step, so those grids keep the plain order.
+    int wg_x = blockIdx.x, wg_y = blockIdx.y;
+    if (gridDim.x <= 8) {
+        const int wg = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        wg_x = wg % gridDim.x; wg_y = wg / gridDim.x;
+    }
+    const int b = wg_y / p.H, h = wg_y % p.H;
+    const int qrow = wg_x * 128 + wave * 32 + l31;
     const bool q_ok = qrow < p.Nq;
     const bf16_t* Qb = p.q + (size_t)b * p.Nq * p.ldq + h * p.D;
     const bf16_t* Gb = p.dout + (size_t)b * p.Nq * p.ldo + h * p.D;
