@@ -122,7 +122,7 @@ class GradBucketReducer:
                 if self.unpack:
                     g.copy_(stage)                               # back to fp32 (the optimizer divides by world)
         else:
-            stage.copy_(g)
+            self._pack(start, end, layers)
             dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
             if self.unpack:
                 g.copy_(stage)

@@ -45,6 +45,23 @@ def _worker(rank, world, port, out):
         out[(rank, step)] = flat.clone() if step == 1 else red.stage_all.float()
         if step == 0:
             assert torch.equal(flat, local)                           # the fp32 buffer keeps the local gradients
+    # step 2: two layers' producers stored their bf16 gradients straight into the staging buffer (`staged`: address ->
+    # floats); the fp32 buffer holds garbage there, which the pack pass must not read
+    red = GradBucketReducer(flat, n_big, packs, bucket_mb=0.03)
+    g = torch.Generator().manual_seed(200 + rank)
+    local = torch.randn(n_big + tail, generator=g)
+    flat[:] = local
+    staged = {}
+    for idx in (1, 4):
+        o, n, _ = packs[idx]
+        red.stage_all[o:o + n] = local[o:o + n].to(torch.bfloat16)
+        flat[o:o + n] = float("nan")
+        staged[flat.data_ptr() + 4 * o] = n
+    red.staged = staged
+    for o, n, pk in reversed(packs):
+        pk.on_grad_ready()
+    red.finish()
+    out[(rank, 2)] = red.stage_all.float()
     dist.destroy_process_group()
 
 
@@ -53,7 +70,7 @@ def test_bucketed_allreduce_world2():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    for step in range(2):
+    for step in range(3):
         locs = [torch.randn(4096 + 1024 + 8192 + 512 + 2048 + 16384 + 300, generator=torch.Generator().manual_seed(100 * step + r))
                 for r in range(world)]
         want = sum(l.to(torch.bfloat16).float() for l in locs)        # bf16 pack, sum, unpack
