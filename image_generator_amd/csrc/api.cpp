@@ -43,7 +43,7 @@ void mi355_prof_begin(int, hipStream_t s, double work) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_open_a = get_event();
     g_open_work = work;
-    if (g_open_a) hipEventRecord(g_open_a, s);
+    if (g_open_a) (void)hipEventRecord(g_open_a, s);
 }
 
 void mi355_prof_end(int fam, hipStream_t s) {
@@ -51,7 +51,7 @@ void mi355_prof_end(int fam, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t b = get_event();
     if (!b) { g_free.push_back(g_open_a); g_open_a = nullptr; return; }
-    hipEventRecord(b, s);
+    (void)hipEventRecord(b, s);
     g_recs.push_back(Rec{fam, g_open_a, b, g_open_work});
     g_open_a = nullptr;
 }
@@ -107,7 +107,7 @@ double mi355_prof_event_overhead_us(void* stream, float* scratch, long long scra
     float bare = 0.f, paired = 0.f;
     ok = ok && hipEventElapsedTime(&bare, outer[0], outer[1]) == hipSuccess &&
          hipEventElapsedTime(&paired, outer[1], outer[2]) == hipSuccess;
-    for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     if (!ok) { mi355_fail(MI355_ERR_LAUNCH, "prof: event calibration failed"); return -1.0; }
     const double us = ((double)paired - (double)bare) / (2.0 * n) * 1e3;
     return us > 0.0 ? us : 0.0;
