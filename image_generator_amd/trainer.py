@@ -95,6 +95,7 @@ class GradBucketReducer:
 
     def reset(self):
         self._counts = [len(pks) for _, _, pks in self.buckets]
+        self._fired = [False] * len(self.buckets)
 
     def _pack(self, start, end, layers):
         """fp32 -> bf16 into the staging buffer, over [start, end) minus the layers whose gradients are staged already."""
@@ -127,19 +128,25 @@ class GradBucketReducer:
             if self.unpack:
                 g.copy_(stage)
 
+    def _launch_bucket(self, b):
+        s, e, _ = self.buckets[b]
+        self._fired[b] = True
+        self._launch(s, e, self._stage[b], self._layers[b])
+
     def _ready(self, b):
         self._counts[b] -= 1
-        if self._counts[b] == 0 and self.active:
-            s, e, _ = self.buckets[b]
-            self._launch(s, e, self._stage[b], self._layers[b])
+        if self._counts[b] == 0 and self.active and not self._fired[b]:
+            self._launch_bucket(b)
 
     def finish(self):
         """Call after backward: flush buckets that never fired, reduce the tail, join the streams."""
         if self.active:
-            for b, c in enumerate(self._counts):
-                if c > 0:
-                    s, e, _ = self.buckets[b]
-                    self._launch(s, e, self._stage[b], self._layers[b])
+            # every bucket that has not gone out yet: layers that did not run backward this step, and a trailing bucket
+            # that holds no signalling layer at all (e.g. only a channel-padded convolution, whose gradient reaches
+            # the buffer through autograd)
+            for b in range(len(self.buckets)):
+                if not self._fired[b]:
+                    self._launch_bucket(b)
             if self.tail[1] > self.tail[0]:
                 self._launch(self.tail[0], self.tail[1], self._tail_stage)
             if self.use_cuda:

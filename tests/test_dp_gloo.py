@@ -62,6 +62,20 @@ def _worker(rank, world, port, out):
         pk.on_grad_ready()
     red.finish()
     out[(rank, 2)] = red.stage_all.float()
+    # step 3: a bucket boundary lands on the last signalling layer and a region without any such layer follows inside
+    # [0, n_big) (the channel-padded output convolution, whose gradient arrives through autograd): that trailing bucket
+    # has no callback to fire it and must still be reduced by finish()
+    extra = 640
+    flat2 = torch.zeros(n_big + extra + tail)
+    red = GradBucketReducer(flat2, n_big + extra, packs, bucket_mb=0.03)
+    assert red.buckets[-1][2] == [] and red.buckets[-1][1] - red.buckets[-1][0] == extra
+    g = torch.Generator().manual_seed(300 + rank)
+    local = torch.randn(n_big + extra + tail, generator=g)
+    flat2[:] = local
+    for o, n, pk in reversed(packs):
+        pk.on_grad_ready()
+    red.finish()
+    out[(rank, 3)] = red.stage_all.float()
     dist.destroy_process_group()
 
 
@@ -78,3 +92,7 @@ def test_bucketed_allreduce_world2():
             got = out[(r, step)]
             assert torch.allclose(got, want, rtol=2e-2, atol=2e-2)
             assert torch.equal(out[(0, step)], got)                   # every rank holds the same reduced gradient
+    n = 4096 + 1024 + 8192 + 512 + 2048 + 16384 + 640 + 300
+    want = sum(torch.randn(n, generator=torch.Generator().manual_seed(300 + r)).to(torch.bfloat16).float() for r in range(world))
+    for r in range(world):
+        assert torch.allclose(out[(r, 3)], want, rtol=2e-2, atol=2e-2)      # the packless bucket included
