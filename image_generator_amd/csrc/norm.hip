@@ -12,6 +12,7 @@
 // No atomics and no stand-alone finalize kernels: the few hundred partial sums a block needs are re-reduced
 // in its prologue, which is cheaper than a dependent launch.
 #include "common.h"
+#include <mutex>
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_grad_f(float z) {
@@ -569,6 +570,52 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
     hipLaunchKernelGGL(gn_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st, (const bf16_t*)x,
                        gpart, stats, gamma, beta, (bf16_t*)y, HW, C, G, rows, silu, eps);
     return mi355_check_launch("groupnorm_fwd");
+}
+
+// GroupNorm forward for callers that cannot allocate (HIP graph capture, serving loops that forbid hipMalloc): the
+// strips' group partials go to a file-scope device array instead of a caller-provided scratch buffer.  Each GPU holds its
+// own copy of the array at its own address, looked up once per device; the kernels get that address as an ordinary
+// argument.  Calls that overlap on one GPU (two streams) race on the array; the partials are overwritten, never
+// accumulated, so nothing has to be cleared between calls.
+constexpr long long GN_STATIC_FLOATS = 256 * 1024;              // 1 MiB per GPU, held until the process ends
+static __device__ __align__(256) float gn_static_scratch[GN_STATIC_FLOATS];
+constexpr int GN_MAX_DEVICES = 64;
+static float* gn_static_ptr[GN_MAX_DEVICES];
+static std::mutex gn_static_mutex;
+
+// Device address of gn_static_scratch on the current device (nullptr + error message on failure).
+static float* gn_static_address() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GN_MAX_DEVICES) {
+        mi355_fail(MI355_ERR_LAUNCH, "groupnorm_fwd_static: no current device (or device index >= %d)", GN_MAX_DEVICES);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(gn_static_mutex);
+    if (!gn_static_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(gn_static_scratch));
+        if (e != hipSuccess || !p) {
+            mi355_fail(MI355_ERR_LAUNCH, "groupnorm_fwd_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        gn_static_ptr[dev] = (float*)p;
+    }
+    return gn_static_ptr[dev];
+}
+
+int mi355_groupnorm_fwd_static(const void* x, const float* gamma, const float* beta, void* y, float* stats, int B, int HW,
+                               int C, int G, float eps, int silu, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd_static: null pointer");
+    if (B < 1 || HW < 1) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd_static: B=%d HW=%d", B, HW);
+    int threads, rpar, rows, strips;
+    if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
+    const long long need = (long long)B * strips * G * 2;       // the forward's part of mi355_groupnorm_scratch_floats()
+    if (need > GN_STATIC_FLOATS)
+        return mi355_fail(MI355_ERR_UNSUPPORTED, "groupnorm_fwd_static: B=%d HW=%d G=%d needs %lld scratch floats, the built-in "
+                          "buffer holds %lld (use mi355_groupnorm_fwd with a caller-provided scratch)", B, HW, G, need, GN_STATIC_FLOATS);
+    float* scratch = gn_static_address();
+    if (!scratch) return MI355_ERR_LAUNCH;
+    return mi355_groupnorm_fwd(x, gamma, beta, y, stats, scratch, B, HW, C, G, eps, silu, stream);
 }
 
 // scratch: mi355_groupnorm_scratch_floats().

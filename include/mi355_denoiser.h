@@ -149,6 +149,15 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
                         const void* dres, void* stream);
+/* mi355_groupnorm_fwd without a scratch argument, for callers that cannot allocate device memory (code under HIP graph
+ * capture, serving loops and harnesses that forbid hipMalloc).  No counterpart in the reference.  The strips' partial
+ * sums live in a 1 MiB device array built into the library (one copy per GPU, held until the process ends), so the
+ * call needs B * strips * G * 2 <= 262144 floats (strips <= 32: e.g. B <= 128 at G = 32) and returns
+ * MI355_ERR_UNSUPPORTED beyond that; it calls no allocating routine.  Same results as mi355_groupnorm_fwd, bit for bit.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race.  The first call
+ * on a device looks the array's address up and must therefore be made outside a stream capture. */
+int mi355_groupnorm_fwd_static(const void* x, const float* gamma, const float* beta, void* y, float* stats, int B, int HW,
+                               int C, int G, float eps, int silu, void* stream);
 /* The reductions that the two backward calls skip when given NULL parameter-gradient pointers, for many layers in
  * one launch: n records of 6 int64 in device memory {partial, out, out_hi | 0, rows, N, split}; out[c] = sum over
  * rows of partial[r][c] for c < split (every c when out_hi is 0), out_hi[c - split] otherwise.  GroupNorm: partial =
