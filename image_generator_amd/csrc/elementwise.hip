@@ -357,18 +357,21 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 }
 // hyper (device floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=bias_corr1 [6]=bias_corr2
 //                        [7]=max_grad_norm (<=0: no clipping) [8]=grad pre-scale (e.g. 1/world)
-// state (device floats): [0]=sum of squared grads (input) ; [1]=skip flag output (1 when non-finite)
+// state (device floats): [0]=sum of squared grads (input) ; [1] += 1 when the update is skipped (non-finite norm)
 // G16: the gradients are bf16 (the all-reduced staging buffer of a data-parallel step, read without unpacking)
 template <int U, bool NT, bool G16 = false>
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const void* __restrict__ gptr, float* __restrict__ m,
                              float* __restrict__ v, bf16_t* __restrict__ p_bf16, const float* __restrict__ hyper,
-                             const float* __restrict__ state, size_t n) {
+                             float* __restrict__ state, size_t n) {
     const float* g = (const float*)gptr;
     const bf16_t* g16 = (const bf16_t*)gptr;
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6];
     const float maxn = hyper[7], pre = hyper[8];
     const float gnorm = sqrtf(state[0]) * pre;
-    if (!(gnorm == gnorm) || gnorm > 3.0e38f) return;          // non-finite gradients: skip the update
+    if (!(gnorm == gnorm) || gnorm > 3.0e38f) {                 // non-finite gradients: skip the update, leave a trace
+        if (blockIdx.x == 0 && threadIdx.x == 0) state[1] += 1.f;
+        return;
+    }
     float scale = pre;
     if (maxn > 0.f) { const float c = maxn / (gnorm + 1e-6f); if (c < 1.f) scale *= c; }
     const float decay = 1.f - lr * wd, rbc2 = 1.f / sqrtf(bc2), step = lr / bc1, omb1 = 1.f - b1, omb2 = 1.f - b2;
@@ -878,7 +881,7 @@ int mi355_zero_ranges(const long long* table, int n, void* stream) {
     hipLaunchKernelGGL(zero_ranges_kernel, dim3(64, n), dim3(256), 0, ST, table);
     return mi355_check_launch("zero_ranges");
 }
-int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
+int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, float* state,
                      long long n, void* stream) {
     if (!p || !g || !m || !v || !hyper || !state) return mi355_fail(MI355_ERR_ARG, "adamw: null pointer");
     if (n & 3) return mi355_fail(MI355_ERR_ARG, "adamw: n must be a multiple of 4 (pad the flat buffer)");
@@ -890,7 +893,7 @@ int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16,
     return mi355_check_launch("adamw");
 }
 // Same step with bf16 gradients (8-byte aligned, n a multiple of 4).
-int mi355_adamw_step_g16(float* p, const void* g16, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
+int mi355_adamw_step_g16(float* p, const void* g16, float* m, float* v, void* p_bf16, const float* hyper, float* state,
                          long long n, void* stream) {
     if (!p || !g16 || !m || !v || !hyper || !state) return mi355_fail(MI355_ERR_ARG, "adamw_g16: null pointer");
     if ((n & 3) || ((uintptr_t)g16 & 7)) return mi355_fail(MI355_ERR_ARG, "adamw_g16: n must be a multiple of 4, gradients 8-byte aligned");

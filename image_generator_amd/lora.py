@@ -132,8 +132,14 @@ class LoraFusedFn(torch.autograd.Function):
     scratch views and the per-step bf16 operands of the skinny GEMMs (Bt16 block-diagonal).  `params` = the 2*S factor parameters
     (A_0, B_0, A_1, B_1, ...) for autograd's bookkeeping."""
 
+    @classmethod
+    def apply_to(cls, x, pack, lf):
+        """Call site helper: the per-step bf16 operands of direct-gradient mode are used only inside a trainer step
+        that records gradients (see LoRALinear.forward)."""
+        return cls.apply(x, pack, lf, torch.is_grad_enabled() and _ops._DIRECT_STEP, *lf.params)
+
     @staticmethod
-    def forward(ctx, x, pack, lf, *params):
+    def forward(ctx, x, pack, lf, direct, *params):
         if not x.is_cuda:
             raise RuntimeError("LoRA: HIP device tensors required (no CPU path)")
         K = x.shape[-1]
@@ -141,9 +147,9 @@ class LoraFusedFn(torch.autograd.Function):
         if x2.dtype != BF16 or not x2.is_contiguous():
             x2 = x2.to(BF16).contiguous()
         M, N, RT = x2.shape[0], pack.n, lf.S * lf.r
-        want = any(ctx.needs_input_grad[3:])
+        want = any(ctx.needs_input_grad[4:])
         W = 8 if RT <= 8 else 16
-        fast = want and lf.grad_dst is not None
+        fast = want and direct and lf.grad_dst is not None
         if fast:        # skinny MFMA GEMM on the per-step bf16 copy of the stacked A factors (see _LoraLinearFn)
             t16 = gemm_skinny(x2, lf.grad_dst[2], lf.alpha)
             y = gemm(x2, pack.w16.view(N, K), lora_t=t16, lora_b=lf.B_all, lora_alpha=1.0, lora_seg=N // lf.S)
@@ -188,14 +194,14 @@ class LoraFusedFn(torch.autograd.Function):
                 gb = _ops.wgrad(dy2, t16, W, N).view(N, W)
                 ga = _ops.wgrad(dt16, x2, K, W).view(W, K)
                 for i in range(S):
-                    if ctx.needs_input_grad[3 + 2 * i]:
-                        grads[2 * i] = ga[i * r:(i + 1) * r]
                     if ctx.needs_input_grad[4 + 2 * i]:
+                        grads[2 * i] = ga[i * r:(i + 1) * r]
+                    if ctx.needs_input_grad[5 + 2 * i]:
                         grads[2 * i + 1] = gb[i * C:(i + 1) * C, i * r:(i + 1) * r]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = gemm(dy2, pack.w16_t.view(K, N), lora_t=dt, lora_b=lf.A_all, lora_alpha=1.0, lora_rmajor=True).view(ctx.xshape)
-        return (dx, None, None, *grads)
+        return (dx, None, None, None, *grads)
 
 
 class LoRALinear(nn.Module):
@@ -216,8 +222,13 @@ class LoRALinear(nn.Module):
     def forward(self, x, residual=None):
         """`residual` (optional, beyond the reference signature) is added in the same GEMM epilogue."""
         w16, w16_t = _operands(self.original)
+        # The direct-gradient operands (bf16 copies of the factors, packed at the start of each trainer step) belong to
+        # that step only: any other forward pass (evaluation or sampling between steps, plain autograd) reads the fp32
+        # factors themselves.  Decided here, because grad mode is always off inside Function.forward and
+        # `ctx.needs_input_grad` does not depend on it.
+        gdst = self.grad_dst if (torch.is_grad_enabled() and _ops._DIRECT_STEP) else None
         return _LoraLinearFn.apply(x, self.lora_A.weight, self.lora_B.weight, self.original.bias, self.alpha, w16, w16_t,
-                                   residual, self.grad_dst)
+                                   residual, gdst)
 
 
 def extract_lora_weights(model):

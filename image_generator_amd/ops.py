@@ -137,6 +137,53 @@ def wgrad(dy, x, cin, cout, ksize=1, stride=1, ups=False, geom=None, out=None, a
     return out
 
 
+class PinnedRing:
+    """Round-robin pinned host buffers behind asynchronous host -> device copies.
+
+    A copy out of pinned memory reads the buffer when the STREAM reaches it, not when the host enqueues it, so a slot may
+    be refilled only after the copy that last read it has run.  Each slot keeps an event recorded right behind its copy;
+    `acquire()` waits for that event on the host, which costs nothing unless the host really is a whole ring ahead of the
+    device (an eager step with no synchronisation lets it run ahead without bound).  A copy enqueued during a stream
+    capture is re-read on every graph replay: its slot is retired into `keep` for the life of the owner and the ring is
+    refilled by the next eager `release()` (host memory cannot be pinned while a capture is open)."""
+
+    def __init__(self, make, size):
+        self._make, self._size = make, size
+        self._bufs = [make() for _ in range(size)]
+        self._evs = [None] * size
+        self._i = 0
+        self.keep = []
+
+    def acquire(self):
+        """The buffer to fill next, safe to overwrite."""
+        ev = self._evs[self._i]
+        if ev is not None:
+            ev.synchronize()
+            self._evs[self._i] = None
+        return self._bufs[self._i]
+
+    def copied(self):
+        """Call on the stream, and right after, the copy out of the acquired buffer was enqueued."""
+        if not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+            self._evs[self._i] = ev
+
+    def release(self):
+        """Move on to the next slot (after `copied()`)."""
+        if torch.cuda.is_current_stream_capturing():
+            self.keep.append(self._bufs.pop(self._i))
+            self._evs.pop(self._i)
+            if not self._bufs:
+                raise RuntimeError("PinnedRing: ring exhausted during graph capture")
+            self._i %= len(self._bufs)
+        else:
+            while len(self._bufs) < self._size:
+                self._bufs.append(self._make())
+                self._evs.append(None)
+            self._i = (self._i + 1) % len(self._bufs)
+
+
 class WgradQueue:
     """Deferred weight gradients: backward pushes (dy, x, destination) jobs, `flush()` runs them as ONE
     grouped launch.  Thousands of tiles in flight keep all 256 CUs busy without aggressive pixel splits
@@ -154,11 +201,8 @@ class WgradQueue:
         self._inflight = []
         self.jb = int(lib.mi355_wgrad_job_bytes())
         self.max_jobs, self.flush_blocks = max_jobs, flush_blocks
-        self._ring = [torch.empty(max_jobs * (self.jb + 16), dtype=torch.uint8).pin_memory() for _ in range(ring)]
-        self._ri = 0
-        self._ring_size = ring
-        self._keep = []          # pinned tables referenced by captured graphs (must outlive them)
-        self._host = self._ring[0]
+        self._ring = PinnedRing(lambda: torch.empty(max_jobs * (self.jb + 16), dtype=torch.uint8).pin_memory(), ring)
+        self._host = self._ring.acquire()
         self._n = 0
         self._blocks = 0
         self._flops = 0.0
@@ -223,6 +267,7 @@ class WgradQueue:
                 for i, (ptr, nb) in enumerate(self._zero):
                     zt[2 * i], zt[2 * i + 1] = ptr, nb
             table.copy_(self._host[:nbytes + 16 * nz], non_blocking=True)
+            self._ring.copied()
             if nz:
                 check(lib.mi355_zero_ranges(table.data_ptr() + nbytes, nz, _stream()), "zero_ranges")
             check(lib.mi355_wgrad_grouped(table.data_ptr(), self._n, self._blocks, self._flops, _stream()), "wgrad_grouped")
@@ -236,18 +281,13 @@ class WgradQueue:
             launch()
         for cb in self._cbs:
             cb()
-        if torch.cuda.is_current_stream_capturing():
-            # the graph re-reads this table on every replay: retire it from the ring (host memory cannot be
-            # pinned while a capture is open, so the ring is refilled by the next eager flush)
-            self._keep.append(self._ring.pop(self._ri))
-            if not self._ring:
-                raise RuntimeError("WgradQueue: pinned table ring exhausted during graph capture")
-            self._ri %= len(self._ring)
-        else:
-            while len(self._ring) < self._ring_size:
-                self._ring.append(torch.empty(self.max_jobs * (self.jb + 16), dtype=torch.uint8).pin_memory())
-            self._ri = (self._ri + 1) % len(self._ring)
-        self._host = self._ring[self._ri]
+        self._ring.release()
+        self._host = self._ring.acquire()
+        self._n, self._blocks, self._flops = 0, 0, 0.0
+        self._refs, self._cbs, self._zero = [], [], []
+
+    def discard(self):
+        """Drop the queued jobs without running them (a step that raised half-way through backward)."""
         self._n, self._blocks, self._flops = 0, 0, 0.0
         self._refs, self._cbs, self._zero = [], [], []
 
@@ -276,9 +316,7 @@ class ReduceQueue:
     def __init__(self, device, max_entries=256, ring=8):
         self.device = device
         self.max_entries = max_entries
-        self._ring = [torch.empty(max_entries * 6, dtype=torch.int64).pin_memory() for _ in range(ring)]
-        self._ring_size, self._ri = ring, 0
-        self._keep = []          # pinned tables referenced by captured graphs
+        self._ring = PinnedRing(lambda: torch.empty(max_entries * 6, dtype=torch.int64).pin_memory(), ring)
         self._entries, self._refs, self._max_cols = [], [], 0
 
     def push(self, partial_ptr, out, out_hi, rows, n, split, scratch):
@@ -288,29 +326,33 @@ class ReduceQueue:
         if len(self._entries) == self.max_entries:
             self.flush()
 
+    def discard(self):
+        self._entries, self._refs, self._max_cols = [], [], 0
+
     def flush(self):
         n = len(self._entries)
         if n == 0:
             return
-        host = self._ring[self._ri]
+        host = self._ring.acquire()
         host[:6 * n] = torch.tensor(self._entries, dtype=torch.int64).view(-1)
         table = torch.empty(6 * n, dtype=torch.int64, device=self.device)
         table.copy_(host[:6 * n], non_blocking=True)
+        self._ring.copied()
         check(lib.mi355_reduce_rows_batched(table.data_ptr(), n, self._max_cols, _stream()), "reduce_rows_batched")
-        if torch.cuda.is_current_stream_capturing():
-            self._keep.append(self._ring.pop(self._ri))     # the graph re-reads this table on every replay
-            if not self._ring:
-                raise RuntimeError("ReduceQueue: pinned table ring exhausted during graph capture")
-            self._ri %= len(self._ring)
-        else:
-            while len(self._ring) < self._ring_size:
-                self._ring.append(torch.empty(self.max_entries * 6, dtype=torch.int64).pin_memory())
-            self._ri = (self._ri + 1) % len(self._ring)
+        self._ring.release()
         self._keep_last = (table, self._refs)       # alive until the next flush (the launch is asynchronous)
         self._entries, self._refs, self._max_cols = [], [], 0
 
 
 _REDUCE_QUEUE = None
+# True while a DenoiserTrainer step runs its forward and backward pass: layers with per-step operands that the trainer
+# prepared (the LoRA adapters' bf16 factor copies) use them only then
+_DIRECT_STEP = False
+
+
+def set_direct_step(on):
+    global _DIRECT_STEP
+    _DIRECT_STEP = bool(on)
 
 
 def set_reduce_queue(q):

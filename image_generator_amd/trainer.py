@@ -178,18 +178,21 @@ class FusedAdamW:
         # partial sums of squares that unsplit weight-gradient jobs add to while they store their results
         self.sq_slots = torch.zeros(int(lib.mi355_wgrad_sumsq_slots()), dtype=F32, device=dev)
         self._sq_tables = {}
-        self._hyper_ring = [torch.zeros(9, dtype=F32).pin_memory() for _ in range(8)]
+        from .ops import PinnedRing
+        self._hyper_ring = PinnedRing(lambda: torch.zeros(9, dtype=F32).pin_memory(), 8)
 
     def set_hyper(self, lr=None, grad_prescale=1.0):
         """Stage the per-step scalars (host -> device copy, asynchronous on the current stream)."""
         if lr is not None:
             self.lr = lr
         self.t += 1
-        h = self._hyper_ring[self.t % len(self._hyper_ring)]   # ring: an in-flight copy never sees the next step's values
+        h = self._hyper_ring.acquire()      # ring: an in-flight copy never sees a later step's values
         h[0], h[1], h[2], h[3], h[4] = self.lr, self.betas[0], self.betas[1], self.eps, self.wd
         h[5], h[6] = 1 - self.betas[0] ** self.t, 1 - self.betas[1] ** self.t
         h[7], h[8] = self.max_norm if self.max_norm else 0.0, grad_prescale
         self.hyper.copy_(h, non_blocking=True)
+        self._hyper_ring.copied()
+        self._hyper_ring.release()
 
     def _uncovered_table(self, covered):
         """Device table for `mi355_sumsq_ranges`: the parts of the flat gradient buffer outside `covered` (address,
@@ -225,7 +228,7 @@ class FusedAdamW:
         only the rest of the buffer."""
         s = _stream()
         n = self.flat.numel()
-        check(lib.mi355_zero_f32(self.state.data_ptr(), 2, s), "zero")
+        check(lib.mi355_zero_f32(self.state.data_ptr(), 1, s), "zero")     # state[1] keeps counting skipped steps
         if covered and grad16 is None:
             table, rows = self._uncovered_table(covered)
             check(lib.mi355_sumsq_ranges(table.data_ptr(), rows, self.state.data_ptr(), s), "sumsq_ranges")
@@ -254,6 +257,14 @@ class FusedAdamW:
     def step(self, lr=None, grad_prescale=1.0, grad16=None, covered=None):
         self.set_hyper(lr, grad_prescale)
         self.apply(grad16, covered)
+
+    def skipped_steps(self):
+        """Host read (synchronises) of how many updates the non-finite guard has skipped so far.  The reference prints
+        `NaN detected` and skips the batch (trainer.py:251-253); here the skip happens on the device and this counter
+        is its trace.  A skipped step still advances the bias-correction step count `t` (torch's GradScaler would not
+        advance the optimizer step): after k skips the corrections are those of step t instead of t - k, a difference
+        that vanishes as beta^t does."""
+        return int(self.state[1])
 
     def grad_norm(self):
         """Host read of the last step's pre-clip global gradient norm (synchronises)."""
@@ -364,22 +375,36 @@ class DenoiserTrainer:
             g = self.opt.grad
             self.wgrad_queue.track_unsplit(g.data_ptr(), g.data_ptr() + 4 * g.numel(), stage16=self.reducer.stage_all)
             self.reducer.staged = self.wgrad_queue.covered_map
-        pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
-        loss = mse_loss(pred, noise)
-        self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched
-        self._ops.set_reduce_queue(self.reduce_queue)
+        self._ops.set_direct_step(True)
         try:
+            pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
+            loss = mse_loss(pred, noise)
+            self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched
+            self._ops.set_reduce_queue(self.reduce_queue)
             loss.backward()
             if self.wgrad_queue is not None:
                 self.wgrad_queue.join()
                 self._covered = list(self.wgrad_queue.covered) if fused else None
             if self.reduce_queue is not None:
                 self.reduce_queue.flush()
+        except BaseException:
+            # a step that dies half-way (the reference's loop catches per-batch exceptions and carries on,
+            # trainer.py:277-280) must not leave half-counted buckets or queued jobs for the next one
+            if self.wgrad_queue is not None:
+                self.wgrad_queue.discard()
+                self.wgrad_queue.track_unsplit()
+            if self.reduce_queue is not None:
+                self.reduce_queue.discard()
+            if self.reducer is not None:
+                self.reducer.reset()
+                self.reducer.staged = None
+            raise
         finally:
             if fused:
                 self.wgrad_queue.track_unsplit()
             self._ops.set_wgrad_queue(None)
             self._ops.set_reduce_queue(None)
+            self._ops.set_direct_step(False)
         self.unet.finish_grads()
         if self.reducer is not None:
             self.reducer.finish()
@@ -449,13 +474,18 @@ class DenoiserTrainer:
     _graph = None
 
     def capture(self, latents, noise, t, ctx):
-        """Capture one full step for these shapes.  Two un-captured warm-up steps run first with lr = 0
-        (weights unchanged; optimizer moments and step count are reset afterwards)."""
+        """Capture one full step for these shapes.  Two un-captured warm-up steps run first with lr = 0 and no weight
+        decay (weights unchanged); the optimizer's moments and step count are put back afterwards, so capturing after
+        `load_checkpoint()` or after eager steps resumes with the AdamW state intact, as the reference's resume does
+        (trainer.py:176-181)."""
         if self.world > 1:
             raise RuntimeError("capture(): the graphed step is single-process; multi-GPU runs the eager step")
         self._static = tuple(x.clone() for x in (latents, noise, t, ctx))
         opt = self.opt
         keep = (opt.lr, opt.wd)
+        saved_t = opt.t
+        # fresh optimizer: the moments are zero and need no copy (2 x 3.4 GB for the full model otherwise)
+        saved_mv = None if saved_t == 0 else (opt.m.clone(), opt.v.clone())
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -467,9 +497,14 @@ class DenoiserTrainer:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         opt.lr, opt.wd = keep
-        opt.m.zero_()
-        opt.v.zero_()
-        opt.t = 0
+        if saved_mv is None:
+            opt.m.zero_()
+            opt.v.zero_()
+        else:
+            opt.m.copy_(saved_mv[0])
+            opt.v.copy_(saved_mv[1])
+            del saved_mv
+        opt.t = saved_t
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_loss = self.forward_backward(*self._static)

@@ -234,10 +234,10 @@ class Attention(nn.Module):
             from .lora import LoraFusedFn
             lf = self.lora_fused
             if self.is_cross:
-                kv = LoraFusedFn.apply(context, self.fused_pack, lf, *lf.params)
+                kv = LoraFusedFn.apply_to(context, self.fused_pack, lf)
                 a = AttentionFn.apply(self.to_q(x).contiguous(), kv, None, self.heads)
             else:
-                a = AttentionFn.apply(LoraFusedFn.apply(x, self.fused_pack, lf, *lf.params), None, None, self.heads)
+                a = AttentionFn.apply(LoraFusedFn.apply_to(x, self.fused_pack, lf), None, None, self.heads)
         else:   # adapters (LoRALinear) wrapped around the projections
             src = context if self.is_cross else x
             a = AttentionFn.apply(self.to_q(x).contiguous(), self.to_k(src).contiguous(), self.to_v(src).contiguous(),

@@ -209,7 +209,9 @@ int mi355_ddim_step_cfg(const float* eps, const float* x, float* out, const floa
 
 /* ---- optimizer (trainer.py:257-259) ---------------------------------------------------------------
  * hyper (device floats): lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_grad_norm,
- * grad pre-scale.  state (device floats): [0] = sum of squared gradients.  Non-finite norm skips. */
+ * grad pre-scale.  state (two device floats): [0] = sum of squared gradients (input); a non-finite norm skips the
+ * update (the reference's NaN guard, trainer.py:247-253, without its host synchronisation) and adds 1 to state[1], which
+ * the library never clears: the caller's count of skipped steps. */
 int mi355_sumsq_f32(const float* g, float* out, long long n, void* stream);
 /* *out += the sum of squares over n ranges in one launch: table (device, int64 pairs) = address of fp32 values, count.
  * A NEGATIVE count marks |count| values that are partial sums already (added as they are): the slots that
@@ -218,7 +220,7 @@ int mi355_sumsq_ranges(const long long* table, int n, float* out, void* stream);
 int mi355_zero_f32(float* p, long long n, void* stream);
 /* Zero n ranges in one launch: table (device, int64 pairs) = address (16-byte aligned), bytes (multiple of 16). */
 int mi355_zero_ranges(const long long* table, int n, void* stream);
-int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, const float* state,
+int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, float* state,
                      long long n, void* stream);
 /* The same two steps on bf16 gradients: a data-parallel step feeds the optimizer the all-reduced bf16 staging
  * buffer directly instead of unpacking it to fp32 first (n a multiple of 8 for the norm, of 4 for the update). */
@@ -229,7 +231,7 @@ int mi355_sumsq_bf16(const void* g16, float* out, long long n, void* stream);
  * to run). */
 int mi355_sumsq_bf16_ordered(const void* g16, float* out, float* partials, int max_partials, long long n, void* stream);
 int mi355_adamw_step_g16(float* p, const void* g16, float* m, float* v, void* p_bf16, const float* hyper,
-                         const float* state, long long n, void* stream);
+                         float* state, long long n, void* stream);
 
 /* ---- LoRA (lora.py:23-24): rank-r side products around the fused GEMM epilogue --------------------*/
 /* t = x A^T (fp32 [M][R]; A may be several adapters' factors stacked, R <= 16).  t16 (optional): bf16 copy

@@ -188,12 +188,14 @@ def test_lora_in_denoiser_attention_projections():
     queue.zero_split_outputs = True
     unet.zero_small_grads(weights_too=False)
     ops.set_wgrad_queue(queue)
+    ops.set_direct_step(True)           # what DenoiserTrainer.forward_backward does around its forward + backward pass
     try:
         loss2 = mse_loss(unet(x.to(D), t.to(D), ctx.to(D)).sample, noise.to(D))
         loss2.backward()
         queue.join()
     finally:
         ops.set_wgrad_queue(None)
+        ops.set_direct_step(False)
     unet.finish_grads()
     assert abs(float(loss2.detach()) - float(loss_ref)) <= 1e-2 * float(loss_ref)
     for n, m in unet.named_modules():
@@ -260,6 +262,54 @@ def test_lora_fused_trainer_step_matches_autograd_path():
     l_graph = [float(tr.train_step(lat, noise, ts, ctx)) for _ in range(3)]
     assert all(math.isfinite(v) for v in l_graph) and l_graph[-1] < losses[0]
     assert math.isfinite(tr.opt.grad_norm()) and tr.opt.grad_norm() > 0
+
+
+def test_lora_forward_outside_a_trainer_step_reads_the_live_factors():
+    """The trainer packs bf16 copies of the adapters' factors at the start of each of its steps.  A forward pass
+    outside such a step - evaluation or sampling between steps (reference trainer.py:294-302), or plain autograd -
+    must read the fp32 factors themselves: building a trainer does not change the network's output, and changing a
+    factor afterwards does."""
+    from image_generator_amd.generator import inject_lora
+    from image_generator_amd.ops import mse_loss
+    from image_generator_amd.trainer import DenoiserTrainer
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    g = torch.Generator().manual_seed(13)
+    lat, noise = torch.randn(4, 4, 8, 8, generator=g).to(D), torch.randn(4, 4, 8, 8, generator=g).to(D)
+    ts, ctx = torch.randint(0, 1000, (4,), generator=g).to(D), torch.randn(4, 16, 64, generator=g).to(D).to(torch.bfloat16)
+    torch.manual_seed(0)
+    unet = UNet2DConditionModel(DenoiserConfig.small()).to(D)
+    adapters = inject_lora(unet, r=4, alpha=1.0)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for ad in adapters:
+            ad.lora_B.weight.normal_(0, 0.1)
+
+    def out():
+        with torch.no_grad():
+            return unet(lat, ts, encoder_hidden_states=ctx).sample.clone()
+
+    y0 = out()
+    tr = DenoiserTrainer(unet, lr=1e-3)
+    assert torch.equal(out(), y0)                       # before any step: no stale (empty) operand copies in use
+    tr.train_step(lat, noise, ts, ctx)
+    y1 = out()
+    with torch.no_grad():
+        for ad in adapters:
+            ad.lora_A.weight.mul_(1.5)
+    y2 = out()
+    assert float((y2 - y1).norm() / y1.norm()) > 1e-3   # the down-projections are read live, not from the step's copy
+    with torch.no_grad():
+        for ad in adapters:
+            ad.lora_A.weight.mul_(1 / 1.5)
+            ad.lora_B.weight.mul_(1.5)
+    y3 = out()
+    assert float((y3 - y2).norm() / y2.norm()) < 2e-2 and float((y3 - y1).norm() / y1.norm()) > 1e-3
+    # plain autograd after a trainer exists: the fp32 path end to end (no queue needed, no stale copies)
+    for p in unet.parameters():
+        p.grad = None
+    loss = mse_loss(unet(lat, ts, encoder_hidden_states=ctx).sample, noise)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in unet.parameters() if p.requires_grad)
 
 
 def test_graphed_step_matches_eager_step():
@@ -403,6 +453,61 @@ def test_checkpoint_round_trip(tmp_path):
     for a, b in zip(cont, resumed):
         assert abs(a - b) <= 1e-3 * abs(a), (cont, resumed)
     assert tr2.load_checkpoint(str(tmp_path / "missing.pth")) is None
+
+    # resume, then capture: the warm-up steps of capture() must hand back the restored AdamW moments and step count
+    torch.manual_seed(321)
+    tr3 = DenoiserTrainer(UNet2DConditionModel(DenoiserConfig.small()).to(D), lr=1e-3)
+    assert tr3.load_checkpoint(path) == 7
+    m0, v0, t0, w0 = tr3.opt.m.clone(), tr3.opt.v.clone(), tr3.opt.t, tr3.opt.flat.clone()
+    assert t0 == 3 and float(m0.abs().max()) > 0
+    tr3.capture(lat, noise, ts, ctx)
+    assert tr3.opt.t == t0 and torch.equal(tr3.opt.m, m0) and torch.equal(tr3.opt.v, v0) and torch.equal(tr3.opt.flat, w0)
+    graphed = [float(tr3.train_step(lat, noise, ts, ctx)) for _ in range(3)]
+    for a, b in zip(cont, graphed):
+        assert abs(a - b) <= 2e-3 * abs(a), (cont, graphed)
+
+
+def test_non_finite_step_is_skipped_and_counted_and_a_failed_step_leaves_no_debris():
+    """A non-finite gradient norm skips the update on the device (the reference's NaN guard, trainer.py:247-253) and the
+    optimizer counts it; a step that raises half-way through leaves the queues and the reducer ready for the next."""
+    import os
+    from image_generator_amd.trainer import DenoiserTrainer
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    g = torch.Generator().manual_seed(12)
+    lat, noise = torch.randn(4, 4, 8, 8, generator=g).to(D), torch.randn(4, 4, 8, 8, generator=g).to(D)
+    ts, ctx = torch.randint(0, 1000, (4,), generator=g).to(D), torch.randn(4, 16, 64, generator=g).to(D).to(torch.bfloat16)
+    torch.manual_seed(0)
+    tr = DenoiserTrainer(UNet2DConditionModel(DenoiserConfig.small()).to(D), lr=1e-3)
+    tr.train_step(lat, noise, ts, ctx)
+    assert tr.opt.skipped_steps() == 0
+    before = tr.opt.flat.clone()
+    bad = lat.clone()
+    bad[0, 0, 0, 0] = float("nan")
+    tr.train_step(bad, noise, ts, ctx)
+    assert tr.opt.skipped_steps() == 1 and torch.equal(before, tr.opt.flat)
+    ok = float(tr.train_step(lat, noise, ts, ctx))
+    assert tr.opt.skipped_steps() == 1 and not torch.equal(before, tr.opt.flat) and math.isfinite(ok)
+
+    # a backward pass that raises: the queued weight-gradient jobs are dropped, the next step is a normal step
+    want = None
+    for fail in (False, True):
+        torch.manual_seed(0)
+        tr = DenoiserTrainer(UNet2DConditionModel(DenoiserConfig.small()).to(D), lr=1e-3)
+        if fail:
+            orig_join = tr.wgrad_queue.join
+            def boom():
+                raise RuntimeError("injected")
+            tr.wgrad_queue.join = boom
+            with pytest.raises(RuntimeError, match="injected"):
+                tr.train_step(lat, noise, ts, ctx)
+            tr.wgrad_queue.join = orig_join
+            assert tr.wgrad_queue._n == 0 and not tr.reduce_queue._entries
+        tr.train_step(lat, noise, ts, ctx)
+        got = tr.opt.grad.clone()
+        if want is None:
+            want = got
+        else:
+            assert float((got - want).norm() / want.norm()) <= 1e-3
 
 
 def test_text_encoder_hip_path_matches_reference_vectors():
