@@ -2,19 +2,27 @@
 """Headline benchmark: denoiser train-step images/sec at 256x256 (latent 32x32), bf16, batch 32 per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without a torchrun environment: this process starts the N ranks itself (`python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, one process per GPU over RCCL) before it touches a GPU, and
+exits with their status; under torchrun (RANK / WORLD_SIZE set) it is one of the ranks.  Fewer visible GPUs than N, or a
+WORLD_SIZE that is not N, is an error - never a silent one-GPU measurement.
 
 One step = DDPM add-noise -> full SD-v1-size UNet forward (text cross-attention, T=77) -> fused MSE ->
 backward (bucketed RCCL gradient all-reduce overlapped on a side stream when N > 1) -> global-norm clip
 + fused AdamW.  Data: synthetic latents / text states resident in HBM, random-init weights (no network).
 Prints ONE JSON line on rank 0 with `roofline` (contraction kernels vs the dense bf16 MFMA peak,
-measured with HIP events on the launch stream) and `cpu_baseline` (the fp32 CPU oracle of the same
-step on a bounded sample, rank 0, N = 1 only).
+measured with HIP events on the launch stream), and at N = 1 also `cpu_baseline` (the fp32 CPU oracle of the same
+step on a bounded sample), `sampler` (the 512x512 sampling loop: 16 images, classifier-free guidance, 50 DDIM steps,
+one HIP graph per step shape) and `lora` (the LoRA fine-tune step at the headline shape).
 """
 import argparse
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,10 +48,101 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU oracle step (32 = the GPU step's own batch, ~15 s on 16 cores)")
     ap.add_argument("--small", action="store_true", help="plumbing-size model (NOT the headline config)")
     ap.add_argument("--no-graph", action="store_true", help="run the eager step even on one GPU")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sampler and LoRA legs of the N = 1 line")
+    ap.add_argument("--sampler-steps", type=int, default=50)
+    ap.add_argument("--lora-steps", type=int, default=20)
     ap.add_argument("--lora", action="store_true",
                     help="LoRA fine-tune step instead of the headline full fine-tune: frozen base, rank-4 adapters on "
                          "attn{1,2}.to_{q,k,v,out} (no cpu_baseline leg)")
     return ap.parse_args()
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources and the modules that choose the launches: a committed counter profile applies to a
+    run only if it was collected from the same code."""
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "image_generator_amd")
+    files = sorted(os.path.join(pkg, "csrc", f) for f in os.listdir(os.path.join(pkg, "csrc"))
+                   if f.endswith((".hip", ".h", ".cpp")))
+    files += [os.path.join(pkg, f) for f in ("ops.py", "unet.py", "trainer.py")]
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n, argv, entry=None, check_devices=True):
+    """Start n ranks of this benchmark (one process per GPU) and return their exit status.  Must run before anything in
+    this process initialises a GPU: counting devices does not."""
+    if check_devices:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} requested but only {have} GPU(s) are visible; not measuring fewer", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC for RCCL between processes
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), entry or os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def sampler_leg(steps, images=16, side=64):
+    """512x512 sampling loop (image_generator.py:73-101 at batch 16): one step = a batch-32 denoiser evaluation +
+    guidance + DDIM update, the whole loop timed (eager first step, graph capture and replays included)."""
+    from image_generator_amd.generator import ImageGenerator
+    torch.manual_seed(0)
+    gen = ImageGenerator("cuda:0", text_encoder_kwargs=dict(num_layers=2))      # the text tower is outside this loop
+    gen.eval()
+    emb = torch.randn(2 * images, 77, 768, device="cuda:0").to(torch.bfloat16)
+    lat = torch.randn(images, 4, side, side, device="cuda:0")
+    gen.sample_latents(emb, lat, 3, 7.5, use_graph=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = gen.sample_latents(emb, lat, steps, 7.5, use_graph=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if not bool(torch.isfinite(out).all()):
+        raise RuntimeError("sampler leg: non-finite latents")
+    flops = 2 * images * 803.9e9 * (side / 64.0) ** 2
+    return {"steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "images": images,
+            "resolution": side * 8, "guidance": 7.5, "hip_graph": True, "mfma_frac": flops * steps / dt / (MFMA_PEAK_TFLOPS * 1e12)}
+
+
+def lora_leg(steps, B=32, L=32):
+    """LoRA fine-tune step (frozen base, rank-4 adapters on attn{1,2}.to_{q,k,v,out}) at the headline shape."""
+    from image_generator_amd.generator import inject_lora
+    from image_generator_amd.trainer import DenoiserTrainer
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    torch.manual_seed(1234)
+    with torch.device("cuda:0"):
+        unet = UNet2DConditionModel(DenoiserConfig.sd_v1())
+    adapters = inject_lora(unet, r=4, alpha=1.0)
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        for ad in adapters:                      # B = 0 at init would leave half of the arithmetic multiplying zeros
+            ad.lora_B.weight.normal_(0, 0.02)
+    tr = DenoiserTrainer(unet, lr=1e-4, weight_decay=1e-2, max_grad_norm=1.0)
+    lat, noise = torch.randn(B, 4, L, L, device="cuda:0"), torch.randn(B, 4, L, L, device="cuda:0")
+    ts = torch.randint(0, 1000, (B,), device="cuda:0")
+    ctx = torch.randn(B, 77, 768, device="cuda:0").to(torch.bfloat16)
+    tr.capture(lat, noise, ts, ctx)
+    for _ in range(3):
+        tr.train_step(lat, noise, ts, ctx)
+    torch.cuda.synchronize()
+    probe = tr.opt.flat[:4096].clone()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step(lat, noise, ts, ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gn = tr.opt.grad_norm()
+    if not (math.isfinite(float(loss)) and math.isfinite(gn) and gn > 0) or torch.equal(probe, tr.opt.flat[:4096]):
+        raise RuntimeError("lora leg: optimizer skipped or diverged")
+    return {"images_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "batch": B,
+            "adapters": len(adapters), "trainable_params": int(tr.opt.flat.numel()), "hip_graph": True,
+            "mfma_frac": 2 * FWD_GFLOP_PER_SAMPLE_256 * 1e9 * B * steps / dt / (MFMA_PEAK_TFLOPS * 1e12)}
 
 
 def cpu_baseline(args):
@@ -73,15 +172,22 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))        # nothing has touched a GPU in this process yet
     from image_generator_amd.trainer import DenoiserTrainer, init_distributed
     from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
     from image_generator_amd._lib import lib
     import torch.distributed as dist
     import ctypes
 
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a line for another world size",
+              file=sys.stderr)
+        sys.exit(2)
     rank, world, local = init_distributed()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise RuntimeError(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     dev = torch.device("cuda", local)
     torch.manual_seed(1234)           # identical initial weights on every rank
     cfg = DenoiserConfig.small() if args.small else DenoiserConfig.sd_v1()
@@ -118,15 +224,24 @@ def main():
         loss = step(i)
     barrier()
     probe = trainer.opt.flat[:65536].clone()      # to prove afterwards that the timed steps really updated the weights
+    if trainer.reducer is not None:
+        trainer.reducer.exposed = []              # (before, after) events around the compute stream's wait for the collectives
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / args.steps * 1e3]
+    comm_exposed = None
+    if trainer.reducer is not None and trainer.reducer.exposed:
+        comm_exposed = sum(a.elapsed_time(b) for a, b in trainer.reducer.exposed) / args.steps
+        trainer.reducer.exposed = None
     if world > 1:
-        tmax = torch.tensor([dt], device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+        every = [torch.zeros(2, device=dev) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([dt, comm_exposed or 0.0], device=dev))
+        rank_ms = [float(e[0]) / args.steps * 1e3 for e in every]
+        comm_exposed = max(float(e[1]) for e in every)
+        dt = max(float(e[0]) for e in every)
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     final_loss = float(loss)
@@ -195,11 +310,16 @@ def main():
             # HBM-side bytes of the same family from the committed rocprofv3 --pmc passes over this workload
             # (tools/pmc_step.sh: counters cannot be read from inside the process), per library call like `achieved`
             traffic, traffic_src = None, None
-            tf_path = os.path.join(ROOT, "profiles", "r01_pmc", "step_traffic.json")
+            tf_path = os.path.join(ROOT, "profiles", "pmc", "step_traffic.json")
             if os.path.exists(tf_path) and not args.small and not args.lora and B == 32 and L == 32:
-                fam = json.load(open(tf_path))["families"]["gemm_conv"]
-                traffic = (fam["fetch_bytes_per_step"] + fam["write_bytes_per_step"]) / max(1.0, gp["launches_per_step"])
-                traffic_src = "profiles/r01_pmc/step_traffic.json (separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE, bytes per call)"
+                rec = json.load(open(tf_path))
+                if rec.get("source_fingerprint") == source_fingerprint():
+                    fam = rec["families"]["gemm_conv"]
+                    traffic = (fam["fetch_bytes_per_step"] + fam["write_bytes_per_step"]) / max(1.0, gp["launches_per_step"])
+                    traffic_src = ("profiles/pmc/step_traffic.json (separate --pmc passes over this code, FETCH_SIZE x2 + "
+                                   "WRITE_SIZE, bytes per call)")
+                else:
+                    traffic_src = "none: the committed counter profile was collected from other kernel sources"
             roof = {"bound": "mfma", "kernel": "gemm_dma_kernel family (implicit-GEMM conv + linear, fwd and dgrad)",
                     "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "event_pair_overhead_us": pair_us,
@@ -224,8 +344,19 @@ def main():
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                           "optimizer": "fused AdamW + global-norm clip", "final_loss": final_loss, "final_grad_norm": gnorm,
                           "hip_graph": bool(graphed)},
+               "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+               "rank_ms_per_step": {"max": max(rank_ms), "min": min(rank_ms)},
+               "comm_exposed_ms_per_step": comm_exposed,
                "step_mfma_frac": step_flops / (ms * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12) if not args.small else None,
                "roofline": roof}
+        if world == 1 and not args.no_extra and not args.small and not args.lora:
+            # the other two workloads of the metric, on the same device, after the headline measurement (its memory freed)
+            del trainer, unet, lat, noise, ctx, ts, probe
+            torch.cuda.empty_cache()
+            out["sampler"] = sampler_leg(args.sampler_steps)
+            torch.cuda.empty_cache()
+            out["lora"] = lora_leg(args.lora_steps)
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and not args.lora:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

@@ -84,6 +84,7 @@ class GradBucketReducer:
         self.tail = (n_big, self.flat_grad.numel())
         self.active = self.world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1"
         self._counts = []
+        self.exposed = None       # a list while someone measures: (before, after) events around finish()'s wait per step
         self.unpack = unpack
         self.stage_all = torch.zeros(self.flat_grad.numel(), dtype=BF16, device=self.device)
         self._stage = [self.stage_all[s:e] for s, e, _ in self.buckets]
@@ -150,7 +151,15 @@ class GradBucketReducer:
             if self.tail[1] > self.tail[0]:
                 self._launch(self.tail[0], self.tail[1], self._tail_stage)
             if self.use_cuda:
-                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+                cur = torch.cuda.current_stream(self.device)
+                if self.exposed is not None:        # measurement: how long the compute stream sits in this wait
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                    cur.wait_stream(self.comm_stream)
+                    e1.record(cur)
+                    self.exposed.append((e0, e1))
+                else:
+                    cur.wait_stream(self.comm_stream)
         self.reset()
 
 

@@ -1,15 +1,19 @@
-"""Rehearsal of bench.py's multi-rank control flow on ONE GPU: two processes, both on cuda:0, rendezvous and collectives
-over gloo through host memory (RCCL refuses two ranks on one device).  Everything else - the reducer, the timed loop,
-the max-over-ranks, the event-timed steps with collectives inside, rank 0 reporting while rank 1 waits - is bench.py's
-own code.  The throughput it prints means nothing.  usage: bench_two_ranks_rehearsal.py [bench.py arguments]"""
-import os, sys, socket
+"""Rehearsal of bench.py's multi-rank path on ONE GPU.  Without a torchrun environment this script calls bench.py's own
+launcher (`launch_ranks`: a `python -m torch.distributed.run` child with two ranks) with itself as the rank program; as
+a rank it puts both processes on cuda:0 and carries rendezvous and collectives over gloo through host memory (RCCL
+refuses two ranks on one device).  Everything else - the launcher, the environment plumbing, the reducer, the timed loop,
+the per-rank times gathered to rank 0, the event-timed steps with collectives inside, rank 0 reporting while rank 1
+waits - is bench.py's own code.  The throughput it prints means nothing.
+usage: bench_two_ranks_rehearsal.py [bench.py arguments other than --gpus]"""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch, torch.distributed as dist, torch.multiprocessing as mp
+import torch, torch.distributed as dist
+import bench
 
 
-def worker(rank, world, port, argv):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+def rank_main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import image_generator_amd.trainer as trainer
 
     def init_gloo():
@@ -17,22 +21,31 @@ def worker(rank, world, port, argv):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         return rank, world, 0
     trainer.init_distributed = init_gloo
-    real = dist.all_reduce
+    real_ar, real_ag = dist.all_reduce, dist.all_gather
 
-    def through_host(t, op=dist.ReduceOp.SUM, group=None):
+    def all_reduce_through_host(t, op=dist.ReduceOp.SUM, group=None):
         if not t.is_cuda:
-            return real(t, op=op, group=group)
+            return real_ar(t, op=op, group=group)
         c = t.float().cpu()
-        real(c, op=op, group=group)
+        real_ar(c, op=op, group=group)
         t.copy_(c)
-    dist.all_reduce = through_host
-    import bench
-    sys.argv = ["bench.py", "--gpus", str(world)] + argv
+
+    def all_gather_through_host(outs, t, group=None):
+        if not t.is_cuda:
+            return real_ag(outs, t, group=group)
+        c = [o.cpu() for o in outs]
+        real_ag(c, t.cpu(), group=group)
+        for o, v in zip(outs, c):
+            o.copy_(v)
+    dist.all_reduce, dist.all_gather = all_reduce_through_host, all_gather_through_host
     bench.main()
 
 
 if __name__ == "__main__":
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    mp.spawn(worker, args=(2, port, sys.argv[1:]), nprocs=2, join=True)
-    print("rehearsal finished")
+    if "RANK" in os.environ:
+        rank_main()
+    else:
+        argv = ["--gpus", "2"] + sys.argv[1:]
+        rc = bench.launch_ranks(2, argv, entry=os.path.abspath(__file__), check_devices=False)
+        print("rehearsal finished, exit status", rc)
+        sys.exit(rc)
