@@ -27,7 +27,8 @@ def _oracle_of(gen):
 def test_generator_surface_and_train_step_parity():
     """train_step(images, captions) returns the reference's scalar objective; the same RNG draws are
     replayed on the device and the denoiser + loss are recomputed by the fp32 CPU oracle
-    (tolerance: 1e-2 relative on the loss, cosine >= 0.98 on every parameter gradient)."""
+    (tolerance: 2e-3 relative on the loss, cosine >= 0.999 on every parameter gradient: the bf16-storage noise floor
+    measured in tests/test_unet_gpu.py is 0.9995)."""
     from oracle import ops_ref
     from oracle.denoiser_ref import mse_objective
     gen = _small_generator()
@@ -55,11 +56,11 @@ def test_generator_surface_and_train_step_parity():
     noisy = ops_ref.ddpm_add_noise(latent.cpu(), noise.cpu(), t.cpu(), ops_ref.sd_alphas_cumprod())
     loss_ref = mse_objective(ref(noisy, t.cpu(), ctx.float().cpu()).sample, noise.cpu())
     loss_ref.backward()
-    assert abs(float(loss.detach()) - float(loss_ref)) <= 1e-2 * float(loss_ref)
+    assert abs(float(loss.detach()) - float(loss_ref)) <= 2e-3 * float(loss_ref)
     rp = dict(ref.named_parameters())
     for n, p in gen.unet.named_parameters():
         a, b = p.grad.float().cpu().flatten(), rp[n].grad.flatten()
-        assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) >= 0.98, n
+        assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) >= 0.999, n
 
 
 def test_caption_dropout_is_per_batch_cpu_rng():
@@ -137,7 +138,8 @@ class _RefLoRA(nn.Module):
 
 def test_lora_in_denoiser_attention_projections():
     """LoRA fine-tune configuration: frozen base, rank-4 adapters on attn{1,2}.to_{q,k,v,out}; loss and adapter
-    gradients against the fp32 oracle with the same adapters (cosine >= 0.98)."""
+    gradients against the fp32 oracle with the same adapters (worst cosine within 3 x the bf16-storage noise floor of
+    these few-hundred-element tensors, and >= 0.998)."""
     from image_generator_amd.generator import inject_lora
     from image_generator_amd.lora import LoRALinear, extract_lora_weights, load_lora_weights
     from image_generator_amd.ops import mse_loss
@@ -169,17 +171,34 @@ def test_lora_in_denoiser_attention_projections():
     loss.backward()
     loss_ref = mse_objective(ref(x, t, ctx).sample, noise)
     loss_ref.backward()
-    assert abs(float(loss.detach()) - float(loss_ref)) <= 1e-2 * float(loss_ref)
+    assert abs(float(loss.detach()) - float(loss_ref)) <= 2e-3 * float(loss_ref)
     trainable = [n for n, p in unet.named_parameters() if p.requires_grad]
     assert trainable and all("lora_" in n for n in trainable)
     assert all(p.grad is None for n, p in unet.named_parameters() if "lora_" not in n)
     ref_mods = dict(ref.named_modules())
-    for n, m in unet.named_modules():
-        if isinstance(m, LoRALinear):
-            rm = ref_mods[n]
-            for got, want in ((m.lora_A.weight.grad, rm.lora_A.grad), (m.lora_B.weight.grad, rm.lora_B.grad)):
-                a, b = got.float().cpu().flatten(), want.flatten()
-                assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) >= 0.98, n
+    # noise floor of bf16 storage for these small tensors (4 x 64 .. 128 x 4 elements average less rounding noise away
+    # than a weight matrix does): the same oracle with bf16-rounded weights and activations
+    from oracle.bf16_emulation import emulate_bf16_storage
+    emu = emulate_bf16_storage(ref)
+    mse_objective(emu(x, t, ctx).sample, noise).backward()
+    emu_mods = dict(emu.named_modules())
+
+    def cos(a, b):
+        a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+        return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+
+    def worst_cosines(direct):
+        worst, floor = 1.0, 1.0
+        for n, m in unet.named_modules():
+            if isinstance(m, LoRALinear):
+                rm, em = ref_mods[n], emu_mods[n]
+                for got, want, fl in ((m.lora_A.weight.grad, rm.lora_A.grad, em.lora_A.grad),
+                                      (m.lora_B.weight.grad, rm.lora_B.grad, em.lora_B.grad)):
+                    worst, floor = min(worst, cos(got, want)), min(floor, cos(fl, want))
+        print(f"adapter gradients ({'direct' if direct else 'autograd'} mode): worst cosine {worst:.5f}, bf16-storage floor {floor:.5f}")
+        assert 1 - worst <= 3 * (1 - floor) and worst >= 0.998, (worst, floor)
+
+    worst_cosines(False)
     # the direct-gradient mode of the fused trainer (skinny MFMA GEMMs + grouped weight-gradient jobs), same inputs,
     # against the same oracle gradients
     from image_generator_amd import ops
@@ -197,13 +216,8 @@ def test_lora_in_denoiser_attention_projections():
         ops.set_wgrad_queue(None)
         ops.set_direct_step(False)
     unet.finish_grads()
-    assert abs(float(loss2.detach()) - float(loss_ref)) <= 1e-2 * float(loss_ref)
-    for n, m in unet.named_modules():
-        if isinstance(m, LoRALinear):
-            rm = ref_mods[n]
-            for got, want in ((m.lora_A.weight.grad, rm.lora_A.grad), (m.lora_B.weight.grad, rm.lora_B.grad)):
-                a, b = got.float().cpu().flatten(), want.flatten()
-                assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) >= 0.98, ("direct", n)
+    assert abs(float(loss2.detach()) - float(loss_ref)) <= 2e-3 * float(loss_ref)
+    worst_cosines(True)
     w = extract_lora_weights(unet)
     assert len(w) == 2 * len(adapters) and all(k.endswith(("lora_A", "lora_B")) for k in w)
     load_lora_weights(unet, w)

@@ -1,12 +1,10 @@
 """End-to-end parity of the HIP denoiser against the fp32 CPU oracle (oracle/denoiser_ref.py) on
 identical weights, seeds and inputs.
 
-Tolerances (stated): the HIP path keeps activations in bf16 (8 significant bits) with fp32
-accumulation, so after ~60 layers we require
-  * output: relative L2 error <= 2e-2,
-  * loss:   |delta| <= 1e-2 relative,
-  * every parameter gradient: cosine similarity >= 0.98 with the oracle gradient and
-    relative L2 error <= 0.2; 95 % of tensors must reach cosine >= 0.995.
+Tolerances: the HIP path keeps weights and activations in bf16 (8 significant bits) with fp32 accumulation.  What that
+alone costs is measured, in the same test, by re-running the oracle with bf16-rounded storage
+(oracle/bf16_emulation.py); the HIP path must stay within twice that floor on the network output and on the worst and
+the median parameter gradient (cosine and relative L2), and every gradient cosine must reach 0.999.
 """
 import pytest
 import torch
@@ -58,6 +56,12 @@ def _cos(a, b):
 @pytest.mark.parametrize("cfg_name,B,hw,T", [("small", 4, 8, 16), ("small", 2, 16, 7), ("sdlike", 2, 16, 77),
                                              ("small", 1, 12, 1), ("small", 3, 20, 5)])
 def test_unet_forward_backward_parity(cfg_name, B, hw, T):
+    """Thresholds come from a measured noise floor, not from a guess: the same oracle is run a second time with the HIP
+    path's storage precision (bf16 weights and activations, fp32 arithmetic; oracle/bf16_emulation.py) and its distance
+    from the fp32 run is what bf16 storage alone costs - worst parameter-gradient cosine 0.9995-0.9998 and relative L2
+    0.02-0.03 on these cases.  The HIP path must stay within TWICE that floor on the worst cosine and the worst relative
+    L2 (measured: 1.1-1.8 x) and within 1.5 x on their medians (measured: 1.0-1.1 x), all evaluated in the same run."""
+    from oracle.bf16_emulation import emulate_bf16_storage, gradient_distances
     from oracle.denoiser_ref import mse_objective
     from image_generator_amd.ops import mse_loss
     ref, hip, rc = _pair(cfg_name)
@@ -65,27 +69,40 @@ def test_unet_forward_backward_parity(cfg_name, B, hw, T):
     out_ref = ref(x, t, ctx).sample
     loss_ref = mse_objective(out_ref, noise)
     loss_ref.backward()
+    emu = emulate_bf16_storage(ref)
+    bf = lambda v: v.to(torch.bfloat16).float()
+    out_emu = emu(bf(x), t, bf(ctx)).sample
+    mse_objective(out_emu, noise).backward()
+    floor = gradient_distances(emu, ref)
     d = "cuda:0"
     out = hip(x.to(d), t.to(d), encoder_hidden_states=ctx.to(d)).sample
     assert out.shape == out_ref.shape and out.dtype == torch.float32
     loss = mse_loss(out, noise.to(d))
     loss.backward()
-    assert _rel(out, out_ref) <= 2e-2, _rel(out, out_ref)
-    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-2 * abs(float(loss_ref.detach())), (float(loss.detach()), float(loss_ref.detach()))
+    out_floor = _rel(out_emu, out_ref)
+    assert _rel(out, out_ref) <= 2 * out_floor, (_rel(out, out_ref), out_floor)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 2e-3 * abs(float(loss_ref.detach())), (float(loss.detach()), float(loss_ref.detach()))
     rp = dict(ref.named_parameters())
-    cosines = []
     for n, p in hip.named_parameters():
         assert p.grad is not None, n
         if float(rp[n].grad.norm()) < 1e-12:
             # one context token: softmax over a single key is 1, so nothing upstream of the cross-attention query has a
             # gradient; the HIP path must produce (numerically) nothing there either
             assert float(p.grad.float().norm()) <= 1e-6, (n, float(p.grad.float().norm()))
-            continue
-        c, r = _cos(p.grad, rp[n].grad), _rel(p.grad, rp[n].grad)
-        cosines.append(c)
-        assert c >= 0.98 and r <= 0.2, (n, c, r)
-    cosines.sort()
-    assert cosines[int(0.05 * len(cosines))] >= 0.995, cosines[:10]
+    got = gradient_distances(hip, ref)
+    assert set(got) == set(floor)
+    worst_cos_f, worst_rel_f = min(c for c, _ in floor.values()), max(r for _, r in floor.values())
+    med = lambda v: sorted(v)[len(v) // 2]
+    med_cos_f, med_rel_f = med([c for c, _ in floor.values()]), med([r for _, r in floor.values()])
+    worst_cos, worst_rel = min(got.items(), key=lambda kv: kv[1][0]), max(got.items(), key=lambda kv: kv[1][1])
+    med_cos, med_rel = med([c for c, _ in got.values()]), med([r for _, r in got.values()])
+    print(f"{cfg_name} B{B} {hw}x{hw} T{T}: output rel-L2 {_rel(out, out_ref):.2e} (floor {out_floor:.2e}); gradient cosine worst "
+          f"{worst_cos[1][0]:.5f} (floor {worst_cos_f:.5f}) median {med_cos:.6f} (floor {med_cos_f:.6f}); relative L2 worst "
+          f"{worst_rel[1][1]:.3e} (floor {worst_rel_f:.3e}) median {med_rel:.3e} (floor {med_rel_f:.3e})")
+    assert 1 - worst_cos[1][0] <= 2 * (1 - worst_cos_f), (worst_cos, worst_cos_f)
+    assert worst_rel[1][1] <= 2 * worst_rel_f, (worst_rel, worst_rel_f)
+    assert 1 - med_cos <= 1.5 * (1 - med_cos_f) and med_rel <= 1.5 * med_rel_f, (med_cos, med_cos_f, med_rel, med_rel_f)
+    assert worst_cos[1][0] >= 0.999          # in absolute terms: every parameter gradient, cosine >= 0.999
 
 
 def test_unet_direct_grads_match_autograd_grads():
