@@ -861,6 +861,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
+// Tuning switches settable at run time (A/B measurements of kernel variants inside one process): mi355_tune_set().
+// No key is read by the committed launchers; an experiment reads g_tune[key] where it picks its variant.
+static int g_tune[16];
+
 template <int BN, int AMODE>
 static int launch_gemm(const GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (128 + BN) * 128;
@@ -1036,6 +1040,12 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
 }
 
 extern "C" {
+
+int mi355_tune_set(int key, int value) {
+    if (key < 0 || key >= 16) return mi355_fail(MI355_ERR_ARG, "tune_set: key %d", key);
+    g_tune[key] = value;
+    return 0;
+}
 
 size_t mi355_gemm_workspace_bytes(int M, int N) {
     // room for up to 16 split-K slabs, capped at 256 MiB (the launcher lowers the split to fit)

@@ -54,6 +54,9 @@ double mi355_prof_event_overhead_us(void* stream, float* scratch, long long scra
  * on registers only (iters a multiple of 8): flops = blocks * 4 * iters * 8 * 16384.  pattern 0: zero operands, 1: mixed-sign changing values.
  * peak_copy: 16-byte-per-lane streaming copy, traffic = 2 * bytes (bytes and both pointers multiples of 16). */
 int mi355_peak_mfma_bf16(float* sink, int blocks, int iters, int pattern, void* stream);
+/* Run-time switch between kernel variants of the contraction launchers, for A/B timing inside one process (measurement
+ * aid, no counterpart in the reference; the defaults are what the product runs).  key 0..15, see csrc/gemm.hip. */
+int mi355_tune_set(int key, int value);
 int mi355_peak_copy(const void* src, void* dst, long long bytes, void* stream);
 
 /* ---- contractions (image_generator.py:124: Linear / Conv2d layers of the denoiser) -------------
