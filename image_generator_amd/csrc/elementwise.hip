@@ -730,6 +730,19 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const long long* __restr
     }
 }
 
+// dst[i] = bf16(src[i]) over many ranges in one launch: record e = {src fp32 address, dst bf16 address, count} (int64),
+// count a multiple of 4, src 16-byte and dst 8-byte aligned; blockIdx.y picks the record.
+__global__ __launch_bounds__(256) void cast_ranges_kernel(const long long* __restrict__ table) {
+    const long long* e = table + 3 * blockIdx.y;
+    const f32x4* src = (const f32x4*)e[0];
+    bf16x4* dst = (bf16x4*)e[1];
+    const long long n4 = e[2] >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = __builtin_nontemporal_load(src + i);
+        dst[i] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    }
+}
+
 extern "C" {
 
 #define ST ((hipStream_t)stream)
@@ -965,6 +978,12 @@ int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, in
         hipLaunchKernelGGL(lora_outer_kernel<false>, dim3(gx, gy), dim3(256), smem, ST, (const bf16_t*)y, t, out, M, C, R, scale,
                            rows, NC, RL, flags & 1);
     return mi355_check_launch("lora_outer");
+}
+int mi355_cast_ranges_f32_to_bf16(const long long* table, int n, int blocks_per_range, void* stream) {
+    if (!table || n < 1 || blocks_per_range < 1 || blocks_per_range > 4096)
+        return mi355_fail(MI355_ERR_ARG, "cast_ranges: bad arguments");
+    hipLaunchKernelGGL(cast_ranges_kernel, dim3(blocks_per_range, n), dim3(256), 0, ST, table);
+    return mi355_check_launch("cast_ranges");
 }
 int mi355_lora_pack(const long long* table, int n, void* stream) {
     if (!table || n < 1) return mi355_fail(MI355_ERR_ARG, "lora_pack: bad arguments");

@@ -84,6 +84,7 @@ class GradBucketReducer:
         self.tail = (n_big, self.flat_grad.numel())
         self.active = self.world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1"
         self._counts = []
+        self._pack_tables = {}
         self.exposed = None       # a list while someone measures: (before, after) events around finish()'s wait per step
         self.unpack = unpack
         self.stage_all = torch.zeros(self.flat_grad.numel(), dtype=BF16, device=self.device)
@@ -99,18 +100,33 @@ class GradBucketReducer:
         self._fired = [False] * len(self.buckets)
 
     def _pack(self, start, end, layers):
-        """fp32 -> bf16 into the staging buffer, over [start, end) minus the layers whose gradients are staged already."""
+        """fp32 -> bf16 into the staging buffer, over [start, end) minus the layers whose gradients are staged already:
+        one table-driven launch of the library (the tables are built once per set of staged layers and kept)."""
         g, st, staged = self.flat_grad, self.stage_all, self.staged
-        cur = start
+        ranges, cur = [], start
         if staged:
             base = g.data_ptr()
             for o, n in layers:
                 if staged.get(base + 4 * o) == n:
                     if o > cur:
-                        st[cur:o].copy_(g[cur:o])
+                        ranges.append((cur, o))
                     cur = o + n
         if cur < end:
-            st[cur:end].copy_(g[cur:end])
+            ranges.append((cur, end))
+        if not ranges:
+            return
+        if not self.use_cuda or any((a % 8) or ((b - a) % 4) for a, b in ranges):
+            for a, b in ranges:
+                st[a:b].copy_(g[a:b])
+            return
+        key = (start, end, tuple(ranges))
+        table = self._pack_tables.get(key)
+        if table is None:
+            rows = [[g.data_ptr() + 4 * a, st.data_ptr() + 2 * a, b - a] for a, b in ranges]
+            table = self._pack_tables[key] = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        longest = max(b - a for a, b in ranges)
+        check(lib.mi355_cast_ranges_f32_to_bf16(table.data_ptr(), table.shape[0], max(1, min(1024, longest // 8192)),
+                                                _stream()), "cast_ranges")
 
     def _launch(self, start, end, stage, layers=()):
         g = self.flat_grad[start:end]
@@ -187,6 +203,9 @@ class FusedAdamW:
         # partial sums of squares that unsplit weight-gradient jobs add to while they store their results
         self.sq_slots = torch.zeros(int(lib.mi355_wgrad_sumsq_slots()), dtype=F32, device=dev)
         self._sq_tables = {}
+        # single-process full fine-tune: the bf16 buffer (laid out like the flat gradient buffer) that unsplit
+        # weight-gradient jobs store into instead of the fp32 buffer; the update then reads 2 bytes per gradient
+        self.stage16 = None
         from .ops import PinnedRing
         self._hyper_ring = PinnedRing(lambda: torch.zeros(9, dtype=F32).pin_memory(), 8)
 
@@ -222,12 +241,17 @@ class FusedAdamW:
             cur = ptr + 4 * cnt
         if cur < hi:
             rows.append((cur, (hi - cur) // 4))
+        pack = None
+        if self.stage16 is not None:        # the same uncovered ranges, as fp32 -> bf16 cast records into the staging buffer
+            if any(((a - lo) // 4) % 8 or c % 4 for a, c in rows):
+                raise RuntimeError("FusedAdamW: gradient ranges are not aligned for the bf16 staging pass")
+            pack = torch.tensor([[a, self.stage16.data_ptr() + (a - lo) // 2, c] for a, c in rows], dtype=torch.int64)
         rows.append((self.sq_slots.data_ptr(), -self.sq_slots.numel()))
         host = torch.tensor(rows, dtype=torch.int64)
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("FusedAdamW: the range table of a captured step must be built by an eager step first")
         table = host.to(self.flat.device)
-        self._sq_tables[key] = (table, len(rows))
+        self._sq_tables[key] = (table, len(rows), None if pack is None else pack.to(self.flat.device))
         return self._sq_tables[key]
 
     def apply(self, grad16=None, covered=None):
@@ -239,10 +263,18 @@ class FusedAdamW:
         n = self.flat.numel()
         check(lib.mi355_zero_f32(self.state.data_ptr(), 1, s), "zero")     # state[1] keeps counting skipped steps
         if covered and grad16 is None:
-            table, rows = self._uncovered_table(covered)
+            table, rows, pack = self._uncovered_table(covered)
             check(lib.mi355_sumsq_ranges(table.data_ptr(), rows, self.state.data_ptr(), s), "sumsq_ranges")
-            check(lib.mi355_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                       self.flat16.data_ptr(), self.hyper.data_ptr(), self.state.data_ptr(), n, s), "adamw")
+            if pack is not None:
+                # the covered gradients are in the bf16 staging buffer already (stored there by their weight-gradient
+                # jobs); cast the rest into it and update from 2-byte gradients: 28 instead of 30 bytes per parameter
+                check(lib.mi355_cast_ranges_f32_to_bf16(pack.data_ptr(), pack.shape[0], 256, s), "cast_ranges")
+                check(lib.mi355_adamw_step_g16(self.flat.data_ptr(), self.stage16.data_ptr(), self.m.data_ptr(),
+                                               self.v.data_ptr(), self.flat16.data_ptr(), self.hyper.data_ptr(),
+                                               self.state.data_ptr(), n, s), "adamw_g16")
+            else:
+                check(lib.mi355_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                           self.flat16.data_ptr(), self.hyper.data_ptr(), self.state.data_ptr(), n, s), "adamw")
             if not self.frozen_base:
                 self.unet.refresh_operands(cast=False)
             return
@@ -266,6 +298,18 @@ class FusedAdamW:
     def step(self, lr=None, grad_prescale=1.0, grad16=None, covered=None):
         self.set_hyper(lr, grad_prescale)
         self.apply(grad16, covered)
+
+    def full_grad(self, covered=None):
+        """The last step's gradient as one fp32 vector laid out like the flat parameter buffer (a copy; for inspection
+        and tests).  With bf16 staging on, the gradients of the `covered` layers (address, floats; the trainer's
+        `_covered`) exist only in `stage16`: they are read from there, everything else from the fp32 buffer."""
+        g = self.grad.clone()
+        if self.stage16 is not None and covered:
+            lo = self.grad.data_ptr()
+            for ptr, cnt in covered:
+                o = (ptr - lo) // 4
+                g[o:o + cnt] = self.stage16[o:o + cnt].float()
+        return g
 
     def skipped_steps(self):
         """Host read (synchronises) of how many updates the non-finite guard has skipped so far.  The reference prints
@@ -359,6 +403,12 @@ class DenoiserTrainer:
         self._fused_sumsq = (self.wgrad_queue is not None and self.reducer is None and not self.opt.frozen_base
                              and os.environ.get("MI355_NO_FUSED_SUMSQ") != "1")
         self._covered = None
+        # ... and store their gradients as bf16 into a staging buffer laid out like the flat gradient buffer (what the
+        # data-parallel step all-reduces and the reference's own reduce_dtype, trainer.py:86-90, is 16-bit too): the
+        # weight-gradient launches write, and the optimizer reads, 2 bytes per gradient instead of 4.  `param.grad` of
+        # those layers is then not materialised (MI355_NO_DIRECT_STAGE=1 restores the fp32 path).
+        if self._fused_sumsq and os.environ.get("MI355_NO_DIRECT_STAGE") != "1" and self.opt.flat.numel() % 8 == 0:
+            self.opt.stage16 = torch.zeros(self.opt.flat.numel(), dtype=BF16, device=dev)
         # data-parallel full fine-tune: unsplit weight-gradient jobs store bf16 straight into the reducer's staging
         # buffer, so the fp32 -> bf16 pack pass touches only what is left (the fp32 buffer and `param.grad` do not
         # hold those gradients then)
@@ -378,7 +428,8 @@ class DenoiserTrainer:
         if fused:
             g = self.opt.grad
             check(lib.mi355_zero_f32(self.opt.sq_slots.data_ptr(), self.opt.sq_slots.numel(), _stream()), "zero")
-            self.wgrad_queue.track_unsplit(g.data_ptr(), g.data_ptr() + 4 * g.numel(), slots=self.opt.sq_slots)
+            self.wgrad_queue.track_unsplit(g.data_ptr(), g.data_ptr() + 4 * g.numel(), slots=self.opt.sq_slots,
+                                           stage16=self.opt.stage16)
         staged = self._direct_stage and self.wgrad_queue is not None
         if staged:
             g = self.opt.grad
@@ -421,6 +472,10 @@ class DenoiserTrainer:
         if staged:
             self.wgrad_queue.track_unsplit()
         return loss.detach()
+
+    def full_grad(self):
+        """fp32 copy of the last step's whole gradient (see FusedAdamW.full_grad)."""
+        return self.opt.full_grad(self._covered)
 
     def train_step(self, latents, noise, t, ctx, epoch_float=None):
         lr = None if epoch_float is None else cosine_warm_restarts_lr(self.base_lr, epoch_float)

@@ -186,6 +186,11 @@ int mi355_silu_bwd_f32(const float* x, const float* dy, float* dx, long long n, 
 int mi355_timestep_embed(const float* t, void* out, int B, int dim, void* stream);          /* cos | sin */
 int mi355_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 int mi355_cast_bf16_to_f32(const void* x, float* y, long long n, void* stream);
+/* dst[i] = bf16(src[i]) over n ranges in ONE launch (the pack pass of the bf16 gradient staging buffer, trainer.py:257-259's
+ * gradients on their way to the optimizer / the all-reduce): table (device) holds n records of 3 int64 {fp32 source
+ * address (16-byte aligned), bf16 destination address (8-byte aligned), count (multiple of 4)}; blocks_per_range
+ * workgroups walk each range. */
+int mi355_cast_ranges_f32_to_bf16(const long long* table, int n, int blocks_per_range, void* stream);
 int mi355_transpose_bf16(const void* in, void* out, int G, int R, int C, void* stream);    /* [G][R][C]->[G][C][R] */
 int mi355_conv_weight_transpose(const void* w, void* wt, int Co, int taps, int Ci, void* stream);
 /* Many weight transposes in ONE launch.  jobs (device, 6 int64 each): src ptr, dst ptr, R, C, T, first tile;

@@ -86,7 +86,10 @@ def test_train_step_closed_form_properties(sd_unet):
     assert n_blocks == 22
 
     # (3) recorded gradient norm == norm of the flat buffer (fp32 tree reduction against an fp64 one)
-    grad = trainer.opt.grad
+    # what the optimizer consumed: with bf16 staging (the default of the single-process full fine-tune) every gradient
+    # reaches it rounded once to bf16 - stored so by the weight-gradient jobs that own their output, cast for the rest
+    grad = trainer.opt.stage16.float() if trainer.opt.stage16 is not None else trainer.opt.grad
+    assert _rel(grad, trainer.full_grad()) <= 3e-3
     gn = float(grad.double().norm())
     assert gn > 0 and abs(trainer.opt.grad_norm() - gn) <= 1e-4 * gn
 
