@@ -17,7 +17,7 @@ HEADER_PATH = os.path.join(_ROOT, "include", "mi355_denoiser.h")
 
 _CTYPES = {
     "int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "long long": ctypes.c_longlong,
-    "double": ctypes.c_double,
+    "double": ctypes.c_double, "unsigned": ctypes.c_uint,
 }
 
 

@@ -18,12 +18,23 @@ struct AttnArgs {
     bf16_t *out, *dq, *dk, *dv;
     float* lse;            // [B][H][Nq]
     float* delta;          // [B][H][Nq]
-    const int* kv_len;     // optional [B]: keys >= kv_len[b] are masked (key-padding mask, forward only); null = all Nk
+    const int* kv_len;     // optional [B]: keys >= kv_len[b] are masked (key-padding mask); null = all Nk
+    unsigned drop_thresh;  // dropout on the attention probabilities: an entry is dropped when its hash < drop_thresh
+    unsigned drop_seed;    //   (= p * 2^32; kernels built with DROP only); kept entries are scaled by drop_scale = 1/(1-p)
+    float drop_scale;
     int B, H, Nq, Nk, D;
     int ldq, ldk, ldv, ldo;
     float scale_log2;      // softmax scale * log2(e)
     float scale;
 };
+
+// Dropout mask of attention entry (query q, key k) of head bh: a counter-based hash, so the forward pass and both backward
+// kernels regenerate the same mask from (seed, position) and nothing is stored.
+__device__ __forceinline__ bool attn_keep(const AttnArgs& p, unsigned bh, unsigned q, unsigned k) {
+    unsigned x = (q * (unsigned)p.Nk + k) * 0x9E3779B1u + bh * 0x85EBCA6Bu + p.drop_seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x >= p.drop_thresh;
+}
 
 // raw v_exp_f32 (arguments here are <= 0 or -inf; no denormal range handling needed)
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
@@ -69,8 +80,9 @@ __device__ __forceinline__ void tile_store(const bf16x8 (&reg)[NCH], char* dst, 
 // =============================================================================================
 // ONES (needs D < 32 * NO): the softmax denominators are accumulated by the P V product itself, through a column of
 // ones in the V tile's padding - 32 fewer additions per lane and key tile in a loop that is VALU-bound at small D.
-template <int ND, int NO, bool ONES>
+template <int ND, int NO, bool ONES, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    static_assert(!(ONES && DROP), "the ones column would sum the dropped probabilities");
     constexpr int DP = 16 * ND;
     constexpr int KLD = DP * 2 + 16;
     constexpr int VLD = tr_ld(NO);
@@ -165,6 +177,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 const float e = EXP2(fmaf(s[kb][r], p.scale_log2, -m_new));
                 s[kb][r] = e;
                 if (!ONES) sum += e;
+                if (DROP) {     // the denominator sums every probability, the product with V only the kept ones
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    s[kb][r] = attn_keep(p, b * p.H + h, qrow, key) ? e * p.drop_scale : 0.f;
+                }
             }
         if (!ONES) {
             sum += __shfl_xor(sum, 32, 64);
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 // =============================================================================================
 // backward: dK, dV.  Workgroup = 128 keys of one (b,h) (32 per wave); loops over 64-query tiles.
 // =============================================================================================
-template <int ND, int NO>
+template <int ND, int NO, bool DROP = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p) {
     constexpr int TLD = tr_ld(NO);      // Q / dO tiles [QT][NO*32], row + transposed reads
     constexpr int QT = 64;              // queries per staged tile (two 32-query MFMA sub-tiles per barrier pair)
@@ -251,7 +267,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
     }
     const int b = wg_y / p.H, h = wg_y % p.H;
     const int key = wg_x * 128 + wave * 32 + l31;
-    const bool k_ok = key < p.Nk;
+    const bool k_ok = key < p.Nk;                                           // a row of dK / dV exists
+    const bool k_valid = key < (p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk);  // and the key is not masked (else its gradients are 0)
     const bf16_t* Qb = p.q + (size_t)b * p.Nq * p.ldq + h * p.D;
     const bf16_t* Gb = p.dout + (size_t)b * p.Nq * p.ldo + h * p.D;
     const bf16_t* Kb = p.k + (size_t)b * p.Nk * p.ldk + h * p.D;
@@ -325,9 +342,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
             float pv = EXP2(fmaf(s[r], p.scale_log2, -Lt[qi]));
-            if (!k_ok) pv = 0.f;
-            const float dsv = pv * (dp[r] - Lt[QT + qi]);
-            pf[r >> 3][r & 7] = (bf16_t)pv;
+            if (!k_valid) pv = 0.f;
+            float pd = pv, dpv = dp[r];
+            if (DROP) {
+                const bool keep = attn_keep(p, b * p.H + h, q0 + qs * 32 + qi, key);
+                pd = keep ? pv * p.drop_scale : 0.f;
+                dpv = keep ? dpv * p.drop_scale : 0.f;
+            }
+            const float dsv = pv * (dpv - Lt[QT + qi]);
+            pf[r >> 3][r & 7] = (bf16_t)pd;
             dsf[r >> 3][r & 7] = (bf16_t)dsv;
         }
 #pragma unroll
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
 // =============================================================================================
 // backward: dQ.  Workgroup = 128 queries of one (b,h) (32 per wave); loops over 64-key tiles.
 // =============================================================================================
-template <int ND, int NO>
+template <int ND, int NO, bool DROP = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
     constexpr int DP = 16 * ND;
     constexpr int KLD = tr_ld(NO);        // K tile: row reads (S^T) + transposed reads (dQ^T)
@@ -429,11 +452,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
 
     const int tr_row = 4 * hh + ((lane & 15) >> 2);
     const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
-    const int nkt = (p.Nk + 63) / 64;
+    const int Nk = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;     // valid keys of this sample
+    const int nkt = (Nk + 63) / 64;
     constexpr int NCK = (64 * NO * 4 + 255) / 256, NCV = (64 * (DP / 8) + 255) / 256;
     bf16x8 kreg[NCK], vreg[NCV];
-    tile_load(kreg, Kb, p.ldk, p.Nk, p.D, 64, NO * 4);
-    tile_load(vreg, Vb, p.ldv, p.Nk, p.D, 64, DP / 8);
+    tile_load(kreg, Kb, p.ldk, Nk, p.D, 64, NO * 4);
+    tile_load(vreg, Vb, p.ldv, Nk, p.D, 64, DP / 8);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
@@ -441,8 +465,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
         tile_store(vreg, Vs, VLD, 64, DP / 8);
         __syncthreads();
         if (kt + 1 < nkt) {
-            tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, p.Nk - k0 - 64, p.D, 64, NO * 4);
-            tile_load(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, p.Nk - k0 - 64, p.D, 64, DP / 8);
+            tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, Nk - k0 - 64, p.D, 64, NO * 4);
+            tile_load(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, Nk - k0 - 64, p.D, 64, DP / 8);
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -461,8 +485,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float pv = EXP2(fmaf(s[r], p.scale_log2, -lse));
-                if (key >= p.Nk) pv = 0.f;
-                dsf[r >> 3][r & 7] = (bf16_t)(pv * (dp[r] - dlt));
+                if (key >= Nk) pv = 0.f;
+                float dpv = dp[r];
+                if (DROP) dpv = attn_keep(p, b * p.H + h, qrow, key) ? dpv * p.drop_scale : 0.f;
+                dsf[r >> 3][r & 7] = (bf16_t)(pv * (dpv - dlt));
             }
 #pragma unroll
             for (int db = 0; db < NO; ++db)
@@ -508,6 +534,32 @@ static int launch_bwd(const AttnArgs& a, hipStream_t s) {
     return mi355_check_launch("attn_bwd");
 }
 
+// The variants with dropout on the attention probabilities (encoder pre-training, encoder/text_encoder.py:16-23): head
+// dims up to 96.
+template <int ND, int NO>
+static int launch_fwd_drop(const AttnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((attn_fwd_kernel<ND, NO, false, true>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    return mi355_check_launch("attn_fwd(dropout)");
+}
+template <int ND, int NO>
+static int launch_bwd_drop(const AttnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<ND, NO, true>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<ND, NO, true>), dim3((a.Nk + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+    return mi355_check_launch("attn_bwd(dropout)");
+}
+#define ATTN_DISPATCH_DROP(FN, a, s)                                     \
+    ((a).D <= 16 ? FN<1, 1>(a, s) : (a).D <= 32 ? FN<2, 1>(a, s)         \
+     : (a).D <= 64 ? FN<4, 2>(a, s) : FN<6, 3>(a, s))
+
+static int set_dropout(AttnArgs& a, float drop_p, unsigned seed) {
+    if (!(drop_p >= 0.f) || drop_p >= 1.f) return mi355_fail(MI355_ERR_ARG, "attention: dropout probability %g", (double)drop_p);
+    if (drop_p > 0.f && a.D > 96) return mi355_fail(MI355_ERR_UNSUPPORTED, "attention: dropout needs head dim <= 96 (got %d)", a.D);
+    a.drop_thresh = (unsigned)((double)drop_p * 4294967296.0);
+    a.drop_scale = 1.f / (1.f - drop_p);
+    a.drop_seed = seed;
+    return 0;
+}
+
 static int check_attn(const AttnArgs& a) {
     if (a.D % 8 || a.D < 8 || a.D > 160) return mi355_fail(MI355_ERR_UNSUPPORTED, "attention: head dim %d (multiple of 8, <= 160)", a.D);
     if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return mi355_fail(MI355_ERR_ARG, "attention: row strides must be multiples of 8");
@@ -549,6 +601,43 @@ int mi355_attention_fwd_masked(const void* q, const void* k, const void* v, void
     if (int rc = check_attn(a)) return rc;
     ProfScope prof(FAM_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Nq * Nk * D);
     return ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
+}
+
+// Forward / backward of the encoder's self-attention in training mode: key-padding mask as valid key counts (kv_len, may
+// be null) and dropout with probability drop_p on the attention probabilities; the mask of an entry is a hash of
+// (seed, head, query, key), so the backward call regenerates it from the same seed.
+int mi355_attention_fwd_train(const void* q, const void* k, const void* v, void* out, float* lse, const int* kv_len,
+                              float drop_p, unsigned seed, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv,
+                              int ldo, float scale, void* stream) {
+    if (!q || !k || !v || !out || !lse) return mi355_fail(MI355_ERR_ARG, "attention_fwd_train: null pointer");
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
+    a.kv_len = kv_len;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    if (int rc = check_attn(a)) return rc;
+    if (int rc = set_dropout(a, drop_p, seed)) return rc;
+    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Nq * Nk * D);
+    if (a.drop_thresh == 0) return ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
+    return ATTN_DISPATCH_DROP(launch_fwd_drop, a, (hipStream_t)stream);
+}
+int mi355_attention_bwd_train(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                              float* delta, void* dq, void* dk, void* dv, const int* kv_len, float drop_p, unsigned seed,
+                              int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale,
+                              void* stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv)
+        return mi355_fail(MI355_ERR_ARG, "attention_bwd_train: null pointer");
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
+    a.dout = (const bf16_t*)dout; a.lse = (float*)lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk;
+    a.dv = (bf16_t*)dv; a.kv_len = kv_len;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    if (int rc = check_attn(a)) return rc;
+    if (int rc = set_dropout(a, drop_p, seed)) return rc;
+    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 14.0 * B * H * (double)Nq * Nk * D);
+    if (a.drop_thresh == 0) return ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
+    return ATTN_DISPATCH_DROP(launch_bwd_drop, a, (hipStream_t)stream);
 }
 
 // delta: scratch [B][H][Nq] floats.  dq uses ldq, dk ldk, dv ldv, dout/o use ldo.

@@ -431,10 +431,19 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
 // ---- symmetric InfoNCE (CLIP-style) on L2-normalised embeddings, one workgroup, B <= 1024
 //   logits = (t_hat . i_hat^T) / clamp(exp(log_temp), 1e-4, 1e4); loss = (CE_rows + CE_cols)/2
 // Outputs loss, d_text, d_image, d_log_temp.  scratch: 4*B*B floats? no: works row-by-row from global logits.
-__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ xh,
-                                                          float* __restrict__ nrm, int B, int D) {
+// grid 2B: blocks [0, B) normalise the text rows, [B, 2B) the image rows; block 0 also clears the two scalars that the
+// later kernels of the same call accumulate into with atomics (no separate zeroing launches)
+__global__ __launch_bounds__(256) void l2norm_pair_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                          float* __restrict__ xh0, float* __restrict__ xh1,
+                                                          float* __restrict__ nrm0, float* __restrict__ nrm1,
+                                                          float* __restrict__ loss, float* __restrict__ dlogtemp, int B, int D) {
     __shared__ float red[16];
-    const int b = blockIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { loss[0] = 0.f; dlogtemp[0] = 0.f; }
+    const bool second = (int)blockIdx.x >= B;
+    const float* x = second ? x1 : x0;
+    float* xh = second ? xh1 : xh0;
+    float* nrm = second ? nrm1 : nrm0;
+    const int b = second ? blockIdx.x - B : blockIdx.x;
     float s = 0.f;
     for (int d = threadIdx.x; d < D; d += blockDim.x) { const float v = x[(size_t)b * D + d]; s += v * v; }
     s = block_sum(s, red);
@@ -492,14 +501,24 @@ __global__ __launch_bounds__(256) void clip_dlogits_kernel(float* __restrict__ l
 }
 // d_xhat[i][:] = sum_j dlogits[i][j] (or [j][i]) * other_hat[j][:] / temp ; then through the L2 normalisation:
 // dx = (d_xhat - xhat * dot(xhat, d_xhat)) / norm
-__global__ __launch_bounds__(256) void clip_dembed_kernel(const float* __restrict__ dlogits, const float* __restrict__ other,
-                                                          const float* __restrict__ xh, const float* __restrict__ nrm,
-                                                          const float* __restrict__ log_temp, float* __restrict__ dx,
-                                                          int B, int D, int transpose) {
+// grid (B, 2): blockIdx.y = 0 text rows (d_text from the rows of dlogits and the image embeddings), 1 image rows (columns of
+// dlogits, text embeddings).  Block (0, 0) also applies the clamp of the temperature to its gradient: every atomic add to
+// it comes from the previous kernel of the call.
+__global__ __launch_bounds__(256) void clip_dembed_kernel(const float* __restrict__ dlogits, const float* __restrict__ th,
+                                                          const float* __restrict__ ih, const float* __restrict__ tn,
+                                                          const float* __restrict__ in_, const float* __restrict__ log_temp,
+                                                          float* __restrict__ d_text, float* __restrict__ d_image,
+                                                          float* __restrict__ dlogtemp, int B, int D) {
     __shared__ float red[16];
     extern __shared__ float dxh[];
-    const int i = blockIdx.x;
-    const float temp = fminf(fmaxf(__expf(log_temp[0]), 1e-4f), 1e4f);
+    const int i = blockIdx.x, transpose = blockIdx.y;
+    const float* other = transpose ? th : ih;
+    const float* xh = transpose ? ih : th;
+    const float* nrm = transpose ? in_ : tn;
+    float* dx = transpose ? d_image : d_text;
+    const float e_t = __expf(log_temp[0]);
+    if (i == 0 && transpose == 0 && threadIdx.x == 0 && (e_t < 1e-4f || e_t > 1e4f)) dlogtemp[0] = 0.f;   // clamp saturated
+    const float temp = fminf(fmaxf(e_t, 1e-4f), 1e4f);
     float dot = 0.f;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float s = 0.f;
@@ -510,10 +529,6 @@ __global__ __launch_bounds__(256) void clip_dembed_kernel(const float* __restric
     }
     dot = block_sum(dot, red);
     for (int d = threadIdx.x; d < D; d += blockDim.x) dx[(size_t)i * D + d] = (dxh[d] - xh[(size_t)i * D + d] * dot) / nrm[i];
-}
-__global__ void clip_temp_clamp_kernel(const float* __restrict__ log_temp, float* __restrict__ dlogtemp) {
-    const float e = __expf(log_temp[0]);
-    if (e < 1e-4f || e > 1e4f) dlogtemp[0] = 0.f;   // clamp saturated: no gradient
 }
 
 // ---- LoRA skinny products
@@ -730,6 +745,67 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const long long* __restr
     }
 }
 
+// ---- dropout for the text encoder's training mode (encoder/text_encoder.py:16-23, dropout 0.2).  The mask of element
+// i is a hash of (seed, i): forward and backward regenerate it, nothing is stored.
+__device__ __forceinline__ bool drop_keep(unsigned long long i, unsigned seed, unsigned thresh) {
+    unsigned x = (unsigned)i * 0x9E3779B1u + (unsigned)(i >> 32) * 0x85EBCA6Bu + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x >= thresh;
+}
+// y = res + dropout(x)   (res may be null; x, res, y bf16, 8 elements per thread)
+__global__ __launch_bounds__(256) void dropout_add_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                          bf16_t* __restrict__ y, size_t n8, unsigned thresh, float scale,
+                                                          unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const bf16x8 v = *(const bf16x8*)(x + i * 8);
+        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (res) r = *(const bf16x8*)(res + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = drop_keep(i * 8 + e, seed, thresh) ? (float)v[e] * scale : 0.f;
+            o[e] = (bf16_t)((float)r[e] + d);
+        }
+        *(bf16x8*)(y + i * 8) = o;
+    }
+}
+// forward: y = dropout(gelu(x));  backward (dy given): dx = dropout(dy) * gelu'(x)
+template <bool BWD>
+__global__ __launch_bounds__(256) void gelu_dropout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           bf16_t* __restrict__ out, size_t n8, unsigned thresh, float scale,
+                                                           unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const bf16x8 v = *(const bf16x8*)(x + i * 8);
+        bf16x8 g = v, o;
+        if (BWD) g = *(const bf16x8*)(dy + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float keep = drop_keep(i * 8 + e, seed, thresh) ? scale : 0.f;
+            o[e] = (bf16_t)(BWD ? (float)g[e] * keep * gelu_grad_f((float)v[e]) : gelu_f((float)v[e]) * keep);
+        }
+        *(bf16x8*)(out + i * 8) = o;
+    }
+}
+// ---- L2 normalisation of fp32 rows (the pooled output, encoder/text_encoder.py:37-40: F.normalize(x, dim=-1))
+// forward: y = x / max(|x|, 1e-12), nrm[b] = that denominator;  backward: dx = (dy - y (y . dy)) / nrm
+template <bool BWD>
+__global__ __launch_bounds__(256) void l2norm_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ out, float* __restrict__ nrm, int D) {
+    __shared__ float red[16];
+    const size_t b = blockIdx.x;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) { const float v = x[b * D + d]; s += BWD ? v * dy[b * D + d] : v * v; }
+    s = block_sum(s, red);
+    if (BWD) {      // x is y here
+        const float inv = 1.f / nrm[b];
+        for (int d = threadIdx.x; d < D; d += 256) out[b * D + d] = (dy[b * D + d] - x[b * D + d] * s) * inv;
+    } else {
+        const float n = fmaxf(sqrtf(s), 1e-12f);
+        if (threadIdx.x == 0) nrm[b] = n;
+        for (int d = threadIdx.x; d < D; d += 256) out[b * D + d] = x[b * D + d] / n;
+    }
+}
+
 // dst[i] = bf16(src[i]) over many ranges in one launch: record e = {src fp32 address, dst bf16 address, count} (int64),
 // count a multiple of 4, src 16-byte and dst 8-byte aligned; blockIdx.y picks the record.
 __global__ __launch_bounds__(256) void cast_ranges_kernel(const long long* __restrict__ table) {
@@ -927,18 +1003,16 @@ int mi355_contrastive_loss_fused(const float* text, const float* image, const fl
     if (B <= 0 || D <= 0 || D > 12288) return mi355_fail(MI355_ERR_ARG, "contrastive: bad shape");
     float* th = scratch; float* ih = th + (size_t)B * D; float* tn = ih + (size_t)B * D; float* in_ = tn + B;
     float* logits = in_ + B; float* lse = logits + (size_t)B * B;
-    mi355_zero_async(loss, sizeof(float), ST);
-    mi355_zero_async(d_log_temp, sizeof(float), ST);
+    // five launches: normalise both inputs (and clear the accumulators), logits, both log-sum-exps, loss + dlogits,
+    // both embedding gradients (and the clamp of the temperature gradient)
     ProfScope prof(FAM_ELEM, ST, 6.0 * B * B * D);
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, ST, text, th, tn, B, D);
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, ST, image, ih, in_, B, D);
+    hipLaunchKernelGGL(l2norm_pair_kernel, dim3(2 * B), dim3(256), 0, ST, text, image, th, ih, tn, in_, loss, d_log_temp, B, D);
     int gx = (B + 3) / 4; if (gx > 64) gx = 64;
     hipLaunchKernelGGL(clip_logits_kernel, dim3(gx, B), dim3(256), 0, ST, th, ih, log_temp, logits, B, D);
     hipLaunchKernelGGL(clip_lse_kernel, dim3(B, 2), dim3(256), 0, ST, logits, lse, B);
     hipLaunchKernelGGL(clip_dlogits_kernel, dim3(B), dim3(256), 0, ST, logits, lse, loss, d_log_temp, B);
-    hipLaunchKernelGGL(clip_temp_clamp_kernel, dim3(1), dim3(1), 0, ST, log_temp, d_log_temp);
-    hipLaunchKernelGGL(clip_dembed_kernel, dim3(B), dim3(256), D * sizeof(float), ST, logits, ih, th, tn, log_temp, d_text, B, D, 0);
-    hipLaunchKernelGGL(clip_dembed_kernel, dim3(B), dim3(256), D * sizeof(float), ST, logits, th, ih, in_, log_temp, d_image, B, D, 1);
+    hipLaunchKernelGGL(clip_dembed_kernel, dim3(B, 2), dim3(256), D * sizeof(float), ST, logits, th, ih, tn, in_, log_temp,
+                       d_text, d_image, d_log_temp, B, D);
     return mi355_check_launch("contrastive_loss_fused");
 }
 
@@ -978,6 +1052,49 @@ int mi355_lora_outer(const void* y, const float* t, float* out, int M, int C, in
         hipLaunchKernelGGL(lora_outer_kernel<false>, dim3(gx, gy), dim3(256), smem, ST, (const bf16_t*)y, t, out, M, C, R, scale,
                            rows, NC, RL, flags & 1);
     return mi355_check_launch("lora_outer");
+}
+static int drop_params(float p, unsigned* thresh, float* scale, const char* what) {
+    if (!(p >= 0.f) || p >= 1.f) return mi355_fail(MI355_ERR_ARG, "%s: dropout probability %g", what, (double)p);
+    *thresh = (unsigned)((double)p * 4294967296.0);
+    *scale = 1.f / (1.f - p);
+    return 0;
+}
+int mi355_dropout_add_bf16(const void* x, const void* residual, void* y, long long n, float p, unsigned seed, void* stream) {
+    if (!x || !y || n < 8 || (n & 7)) return mi355_fail(MI355_ERR_ARG, "dropout_add: bad arguments (n a multiple of 8)");
+    unsigned th; float sc;
+    if (int rc = drop_params(p, &th, &sc, "dropout_add")) return rc;
+    ProfScope prof(FAM_ELEM, ST, (double)n * (residual ? 6 : 4));
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(GRID_FOR((size_t)n / 8, 256)), dim3(256), 0, ST, (const bf16_t*)x,
+                       (const bf16_t*)residual, (bf16_t*)y, (size_t)n / 8, th, sc, seed);
+    return mi355_check_launch("dropout_add");
+}
+int mi355_gelu_dropout_fwd(const void* x, void* y, long long n, float p, unsigned seed, void* stream) {
+    if (!x || !y || n < 8 || (n & 7)) return mi355_fail(MI355_ERR_ARG, "gelu_dropout_fwd: bad arguments (n a multiple of 8)");
+    unsigned th; float sc;
+    if (int rc = drop_params(p, &th, &sc, "gelu_dropout")) return rc;
+    ProfScope prof(FAM_ELEM, ST, (double)n * 4);
+    hipLaunchKernelGGL(gelu_dropout_kernel<false>, dim3(GRID_FOR((size_t)n / 8, 256)), dim3(256), 0, ST, (const bf16_t*)x,
+                       (const bf16_t*)nullptr, (bf16_t*)y, (size_t)n / 8, th, sc, seed);
+    return mi355_check_launch("gelu_dropout_fwd");
+}
+int mi355_gelu_dropout_bwd(const void* x, const void* dy, void* dx, long long n, float p, unsigned seed, void* stream) {
+    if (!x || !dy || !dx || n < 8 || (n & 7)) return mi355_fail(MI355_ERR_ARG, "gelu_dropout_bwd: bad arguments (n a multiple of 8)");
+    unsigned th; float sc;
+    if (int rc = drop_params(p, &th, &sc, "gelu_dropout")) return rc;
+    ProfScope prof(FAM_ELEM, ST, (double)n * 6);
+    hipLaunchKernelGGL(gelu_dropout_kernel<true>, dim3(GRID_FOR((size_t)n / 8, 256)), dim3(256), 0, ST, (const bf16_t*)x,
+                       (const bf16_t*)dy, (bf16_t*)dx, (size_t)n / 8, th, sc, seed);
+    return mi355_check_launch("gelu_dropout_bwd");
+}
+int mi355_l2norm_rows_f32(const float* x, float* y, float* norms, int B, int D, void* stream) {
+    if (!x || !y || !norms || B < 1 || D < 1) return mi355_fail(MI355_ERR_ARG, "l2norm_rows: bad arguments");
+    hipLaunchKernelGGL(l2norm_f32_kernel<false>, dim3(B), dim3(256), 0, ST, x, (const float*)nullptr, y, norms, D);
+    return mi355_check_launch("l2norm_rows");
+}
+int mi355_l2norm_rows_bwd_f32(const float* y, const float* norms, const float* dy, float* dx, int B, int D, void* stream) {
+    if (!y || !norms || !dy || !dx || B < 1 || D < 1) return mi355_fail(MI355_ERR_ARG, "l2norm_rows_bwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_f32_kernel<true>, dim3(B), dim3(256), 0, ST, y, dy, dx, (float*)norms, D);
+    return mi355_check_launch("l2norm_rows_bwd");
 }
 int mi355_cast_ranges_f32_to_bf16(const long long* table, int n, int blocks_per_range, void* stream) {
     if (!table || n < 1 || blocks_per_range < 1 || blocks_per_range > 4096)

@@ -12,8 +12,13 @@ tokens leave the layer stack as zeros before the final LayerNorm/projection.  Th
 (`return_pooled=False`, no gradients, HIP device) runs on the library's kernels: fused in-projection GEMM,
 flash attention with the key-padding mask as per-sample key counts, out-projection / feed-forward GEMMs
 with the residual in the epilogue, LayerNorm and GELU kernels; bf16 activations, fp32 accumulation.
-In training mode (encoder pre-training, outside the denoiser hot path) and for the pooled output the
-arithmetic is issued through PyTorch tensor ops: every row is computed and dropout applies.
+Training mode (the contrastive pre-training of encoder/train_encoder.py:83-110) and the pooled output run on the same
+kernels through autograd Functions: every row is computed, as the reference's training path does, the key-padding mask
+and the dropout on the attention probabilities live inside the flash-attention kernels (forward and backward), the other
+three dropouts of a layer are fused with the residual add / the GELU, and the pooled output is L2-normalised by a row
+kernel.  Dropout masks are hashes of (seed, position): they are regenerated in the backward pass, never stored; the
+seed of a forward pass is drawn from torch's CPU generator, so `torch.manual_seed` makes a run repeatable (the masks are
+not torch's own: the two random streams differ, the statistics do not).  CPU tensors take the PyTorch tensor ops below.
 """
 from __future__ import annotations
 
@@ -22,6 +27,140 @@ import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+def _kernels():
+    from . import ops
+    from ._lib import lib, check
+    return ops, lib, check
+
+
+class _ToBf16Fn(torch.autograd.Function):
+    """fp32 -> bf16 (the embedding rows on their way into the first GEMM); gradient back as fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ops, lib, check = _kernels()
+        return ops.cast_bf16(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops, lib, check = _kernels()
+        dy = dy.contiguous()
+        dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+        check(lib.mi355_cast_bf16_to_f32(dy.data_ptr(), dx.data_ptr(), dy.numel(), ops._stream()), "cast")
+        return dx
+
+
+class _AttnTrainFn(torch.autograd.Function):
+    """Self-attention on the fused q/k/v projection output [B, T, 3D] with the key-padding mask (valid key counts) and
+    dropout on the attention probabilities, both inside the flash kernels."""
+
+    @staticmethod
+    def forward(ctx, qkv, kv_len, heads, p, seed):
+        ops, lib, check = _kernels()
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        d = C // heads
+        out = torch.empty((B, T, C), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
+        q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+        check(lib.mi355_attention_fwd_train(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                            None if kv_len is None else kv_len.data_ptr(), p, seed, B, heads, T, T, d,
+                                            C3, C3, C3, C, d ** -0.5, ops._stream()), "attention_fwd_train")
+        ctx.save_for_backward(qkv, out, lse, kv_len)
+        ctx.meta = (heads, p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        ops, lib, check = _kernels()
+        qkv, out, lse, kv_len = ctx.saved_tensors
+        heads, p, seed = ctx.meta
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        d = C // heads
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+        dq, dk, dv = dqkv[:, :, :C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:]
+        check(lib.mi355_attention_bwd_train(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), do.data_ptr(),
+                                            lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                            None if kv_len is None else kv_len.data_ptr(), p, seed, B, heads, T, T, d,
+                                            C3, C3, C3, C, d ** -0.5, ops._stream()), "attention_bwd_train")
+        return dqkv, None, None, None, None
+
+
+class _DropoutAddFn(torch.autograd.Function):
+    """y = residual + dropout_p(x): the dropout behind the attention / feed-forward output projection and the residual
+    add in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p, seed):
+        ops, lib, check = _kernels()
+        x, residual = x.contiguous(), residual.contiguous()
+        y = torch.empty_like(x)
+        check(lib.mi355_dropout_add_bf16(x.data_ptr(), residual.data_ptr(), y.data_ptr(), x.numel(), p, seed, ops._stream()),
+              "dropout_add")
+        ctx.meta = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops, lib, check = _kernels()
+        p, seed = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.mi355_dropout_add_bf16(dy.data_ptr(), None, dx.data_ptr(), dy.numel(), p, seed, ops._stream()), "dropout_add")
+        return dx, dy, None, None
+
+
+class _GeluDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ops, lib, check = _kernels()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.mi355_gelu_dropout_fwd(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, ops._stream()), "gelu_dropout_fwd")
+        ctx.save_for_backward(x)
+        ctx.meta = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops, lib, check = _kernels()
+        (x,) = ctx.saved_tensors
+        p, seed = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.mi355_gelu_dropout_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), p, seed, ops._stream()),
+              "gelu_dropout_bwd")
+        return dx, None, None
+
+
+class _L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) on fp32 rows (the pooled output)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ops, lib, check = _kernels()
+        x = x.contiguous()
+        B, D = x.shape
+        y, nrm = torch.empty_like(x), torch.empty(B, dtype=torch.float32, device=x.device)
+        check(lib.mi355_l2norm_rows_f32(x.data_ptr(), y.data_ptr(), nrm.data_ptr(), B, D, ops._stream()), "l2norm_rows")
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops, lib, check = _kernels()
+        y, nrm = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(lib.mi355_l2norm_rows_bwd_f32(y.data_ptr(), nrm.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.shape[0], y.shape[1],
+                                            ops._stream()), "l2norm_rows_bwd")
+        return dx
 
 
 class _SelfAttn(nn.Module):
@@ -75,30 +214,14 @@ class TextEncoder(nn.Module):
         self.projection = nn.Linear(embed_dim, projection_dim)
 
     # ---- inference on the HIP kernels -----------------------------------------------------------
-    def _operands(self):
-        """bf16 copies of the GEMM weights, rebuilt when a parameter changes (the module is frozen in the generator)."""
-        sig = tuple(p._version for p in self.parameters()) + (next(self.parameters()).device,)
-        if getattr(self, "_op_sig", None) != sig:
-            from .ops import BF16
-            self._w16 = {n: p.detach().to(BF16).contiguous() for n, p in self.named_parameters()
-                         if p.dim() == 2 and not n.startswith("embedding")}
-            self._op_sig = sig
-        return self._w16
-
     def _forward_hip(self, input_ids, attention_mask):
         from . import ops
-        w16 = self._operands()
+        w16 = {n: pk.w16 for n, pk in self._train_packs().items()}     # one set of bf16 operand copies for both paths
         B, T = input_ids.shape
         D = self.embedding.embedding_dim
         H = self.transformer.layers[0].self_attn.num_heads
         x = ops.cast_bf16(self.embedding(input_ids).contiguous()).view(B * T, D)      # gather, then fp32 -> bf16
-        kv_len = None
-        if attention_mask is not None:
-            m = attention_mask.bool()
-            kv_len = m.sum(dim=1).to(torch.int32)
-            # the kernel takes the mask as a count of leading keys: tokenizers pad on the right
-            if not bool((m == (torch.arange(T, device=m.device)[None, :] < kv_len[:, None])).all()) or int(kv_len.min()) < 1:
-                return None
+        kv_len = self._key_counts(attention_mask)
         for i, layer in enumerate(self.transformer.layers):
             pre = f"transformer.layers.{i}."
             sa = layer.self_attn
@@ -115,13 +238,105 @@ class TextEncoder(nn.Module):
         y = ops.gemm(x, w16["projection.weight"], bias=self.projection.bias, out_fp32=True)
         return y.view(B, T, -1)
 
+    # The kernels take the key-padding mask as a count of leading valid keys per sample: tokenizers pad on the right
+    # (tokenizer/tokenizer.py:4-9 sets no padding side, the library default is right).  By default that is trusted - checking
+    # it costs a host synchronisation inside every `encode_text` / training step; `check_mask_layout = True` verifies
+    # it and raises instead of computing something else.
+    check_mask_layout = False
+
+    def _key_counts(self, attention_mask):
+        if attention_mask is None:
+            return None
+        m = attention_mask.bool()
+        kv_len = m.sum(dim=1).to(torch.int32)
+        if self.check_mask_layout:
+            T = m.shape[1]
+            if not bool((m == (torch.arange(T, device=m.device)[None, :] < kv_len[:, None])).all()) or int(kv_len.min()) < 1:
+                raise ValueError("TextEncoder: attention_mask must be right-padded with at least one valid token per row "
+                                 "(the HIP attention kernels take the mask as valid-key counts)")
+        return kv_len.clamp_(min=1)
+
+    def _train_packs(self):
+        """Operand packs (bf16 [N][K] and its transpose) of every weight matrix for the training path, rebuilt when a
+        parameter changed; a trainer that updates the masters and the bf16 copies itself calls `operands_current()`."""
+        from .ops import BF16, WeightPack, _stream
+        from ._lib import lib, check
+        sig = tuple(p._version for p in self.parameters()) + (next(self.parameters()).device,)
+        if getattr(self, "_pack_sig", None) != sig or getattr(self, "_packs", None) is None:
+            packs = {}
+            for n, p in self.named_parameters():
+                if p.dim() != 2 or n.startswith("embedding"):
+                    continue
+                pk = WeightPack()
+                pk.n, pk.k = p.shape
+                old = getattr(self, "_packs", None)
+                if old is not None and n in old and old[n].w16.shape == p.shape:      # keep the buffers (addresses stay valid)
+                    pk.w16, pk.w16_t = old[n].w16, old[n].w16_t
+                    pk.w16.copy_(p.detach())
+                else:
+                    pk.w16 = p.detach().to(BF16).contiguous()
+                    pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=p.device)
+                check(lib.mi355_transpose_bf16(pk.w16.data_ptr(), pk.w16_t.data_ptr(), 1, pk.n, pk.k, _stream()), "transpose")
+                packs[n] = pk
+            self._packs, self._pack_sig = packs, sig
+        return self._packs
+
+    def operands_current(self):
+        """Tell the module its bf16 operand packs already match the fp32 masters (a fused optimizer wrote both)."""
+        self._pack_sig = tuple(p._version for p in self.parameters()) + (next(self.parameters()).device,)
+
+    def _forward_train_hip(self, input_ids, attention_mask, return_pooled):
+        """Every row computed, dropout active when `self.training`: the reference's training arithmetic
+        (encoder/text_encoder.py:29-43 under train_encoder.py:103-105) on the library's kernels, differentiable."""
+        from .ops import LinearFn, LayerNormFn
+        packs = self._train_packs()
+        B, T = input_ids.shape
+        D = self.embedding.embedding_dim
+        H = self.transformer.layers[0].self_attn.num_heads
+        p = float(self.transformer.layers[0].p) if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,))) if p > 0 else 0     # CPU generator: no device synchronisation
+        kv_len = self._key_counts(attention_mask)
+        x = _ToBf16Fn.apply(self.embedding(input_ids)).view(B * T, D)
+        for i, layer in enumerate(self.transformer.layers):
+            pre = f"transformer.layers.{i}."
+            sa = layer.self_attn
+            s0 = (seed + 7919 * (4 * i + 1)) & 0x7FFFFFFF
+            qkv = LinearFn.apply(x, packs[pre + "self_attn.in_proj_weight"], sa.in_proj_bias, None, False, sa.in_proj_weight)
+            a = _AttnTrainFn.apply(qkv.view(B, T, 3 * D), kv_len, H, p, s0).view(B * T, D)
+            if p > 0:
+                a = LinearFn.apply(a, packs[pre + "self_attn.out_proj.weight"], sa.out_proj.bias, None, False, sa.out_proj.weight)
+                h = _DropoutAddFn.apply(a, x, p, s0 + 1)
+            else:
+                h = LinearFn.apply(a, packs[pre + "self_attn.out_proj.weight"], sa.out_proj.bias, x, False, sa.out_proj.weight)
+            x = LayerNormFn.apply(h, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+            f = LinearFn.apply(x, packs[pre + "linear1.weight"], layer.linear1.bias, None, False, layer.linear1.weight)
+            f = _GeluDropoutFn.apply(f, p, s0 + 2)
+            if p > 0:
+                f = LinearFn.apply(f, packs[pre + "linear2.weight"], layer.linear2.bias, None, False, layer.linear2.weight)
+                h = _DropoutAddFn.apply(f, x, p, s0 + 3)
+            else:
+                h = LinearFn.apply(f, packs[pre + "linear2.weight"], layer.linear2.bias, x, False, layer.linear2.weight)
+            x = LayerNormFn.apply(h, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+        if return_pooled:       # LayerNorm and projection are per row: only the first token's rows are needed
+            x0 = x.view(B, T, D)[:, 0].contiguous()
+            x0 = LayerNormFn.apply(x0, self.norm.weight, self.norm.bias, self.norm.eps)
+            y = LinearFn.apply(x0, packs["projection.weight"], self.projection.bias, None, True, self.projection.weight)
+            return _L2NormFn.apply(y)
+        x = LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        y = LinearFn.apply(x, packs["projection.weight"], self.projection.bias, None, True, self.projection.weight)
+        return y.view(B, T, -1)
+
+    def _hip_ok(self, input_ids):
+        d = self.embedding.embedding_dim
+        h = self.transformer.layers[0].self_attn.num_heads
+        return input_ids.is_cuda and d % 8 == 0 and (d // h) % 8 == 0 and d // h <= 96
+
     def forward(self, input_ids, attention_mask, return_pooled=True):
-        if (not return_pooled and input_ids.is_cuda and not (self.training and torch.is_grad_enabled())
-                and not torch.is_grad_enabled() and self.embedding.embedding_dim % 8 == 0
-                and (self.embedding.embedding_dim // self.transformer.layers[0].self_attn.num_heads) % 8 == 0):
-            y = self._forward_hip(input_ids, attention_mask)
-            if y is not None:
-                return y
+        if self._hip_ok(input_ids):
+            train_path = torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters()))
+            if train_path or return_pooled:
+                return self._forward_train_hip(input_ids, attention_mask, return_pooled)
+            return self._forward_hip(input_ids, attention_mask)
         x = self.embedding(input_ids)
         pad = ~attention_mask.bool() if attention_mask is not None else None
         for layer in self.transformer.layers:

@@ -141,6 +141,19 @@ int mi355_attention_bwd(const void* q, const void* k, const void* v, const void*
                         float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int D, int ldq,
                         int ldk, int ldv, int ldo, float scale, void* stream);
 
+/* Self-attention of the text encoder in TRAINING mode (encoder/text_encoder.py:16-23,31-34 as run by
+ * encoder/train_encoder.py:103-105): the key-padding mask as valid key counts (kv_len, device int32 [B], or NULL) and
+ * dropout with probability drop_p on the attention probabilities, forward and backward.  The dropout mask of an entry
+ * is a hash of (seed, head, query, key): pass the same seed to the backward call; nothing is stored.  drop_p = 0 runs
+ * the plain kernels (any head dim <= 160); drop_p > 0 needs D <= 96.  Gradients of masked keys are written as zeros. */
+int mi355_attention_fwd_train(const void* q, const void* k, const void* v, void* out, float* lse, const int* kv_len,
+                              float drop_p, unsigned seed, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv,
+                              int ldo, float scale, void* stream);
+int mi355_attention_bwd_train(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                              float* delta, void* dq, void* dk, void* dv, const int* kv_len, float drop_p, unsigned seed,
+                              int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale,
+                              void* stream);
+
 /* ---- normalisation ------------------------------------------------------------------------------
  * GroupNorm over [B][HW][C] with G groups, optional fused SiLU.  stats [B][G][2] = (mean, rstd).
  * scratch (both calls): mi355_groupnorm_scratch_floats(B, HW, C, G) floats.
@@ -179,6 +192,18 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
 /* out[m][:] = softmax(scale * in[m][:]) over bf16 rows (single-head attention of the auto-encoder mid block) */
 int mi355_softmax_rows_bf16(const void* in, void* out, int M, int N, float scale, void* stream);
 int mi355_gelu_bf16(const void* in, void* out, long long n, void* stream);                   /* erf GELU (text_encoder.py:22) */
+/* Training mode of the text encoder (encoder/text_encoder.py:16-23: TransformerEncoderLayer(dropout=0.2, activation='gelu')).
+ * The dropout mask of element i is a hash of (seed, i): the backward call regenerates it from the same seed, nothing is
+ * stored.  n a multiple of 8, bf16.
+ *   dropout_add : y = residual + dropout_p(x)   (residual may be NULL; backward of x: the same call on dy without residual)
+ *   gelu_dropout: y = dropout_p(gelu_erf(x));  backward: dx = dropout_p(dy) * gelu_erf'(x) */
+int mi355_dropout_add_bf16(const void* x, const void* residual, void* y, long long n, float p, unsigned seed, void* stream);
+int mi355_gelu_dropout_fwd(const void* x, void* y, long long n, float p, unsigned seed, void* stream);
+int mi355_gelu_dropout_bwd(const void* x, const void* dy, void* dx, long long n, float p, unsigned seed, void* stream);
+/* Pooled output (encoder/text_encoder.py:37-40 F.normalize): y = x / max(|x|, 1e-12) per fp32 row, norms[b] = the
+ * denominator; backward dx = (dy - y (y . dy)) / norms. */
+int mi355_l2norm_rows_f32(const float* x, float* y, float* norms, int B, int D, void* stream);
+int mi355_l2norm_rows_bwd_f32(const float* y, const float* norms, const float* dy, float* dx, int B, int D, void* stream);
 int mi355_geglu_fwd(const void* in, void* out, long long M, int F, void* stream);           /* in [M][2F] */
 int mi355_geglu_bwd(const void* in, const void* dout, void* din, long long M, int F, void* stream);
 int mi355_silu_f32_to_bf16(const float* x, void* y, long long n, void* stream);

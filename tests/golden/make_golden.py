@@ -111,6 +111,39 @@ def text_encoder_golden():
                "n_keys": len(d.state_dict())}, open(os.path.join(HERE, "text_encoder_meta.json"), "w"), indent=1)
 
 
+def encoder_step_golden():
+    """One contrastive pre-training step of the reference (encoder/train_encoder.py:103-108: TextEncoder in training
+    mode -> pooled embeddings -> ContrastiveLoss against image embeddings -> backward), dropout disabled so that the
+    arithmetic is reproducible: inputs, weights, loss and the gradient of every parameter."""
+    from encoder.text_encoder import TextEncoder
+    from loss import ContrastiveLoss
+    torch.manual_seed(400)
+    m = TextEncoder(vocab_size=300, embed_dim=96, num_layers=2, n_head=4, projection_dim=64, dropout=0.2)
+    crit = ContrastiveLoss(0.07)
+    B, T = 8, 12
+    lens = torch.tensor([12, 5, 9, 1, 12, 7, 3, 10])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).long()
+    ids = torch.randint(4, 300, (B, T)) * mask
+    ids[:, 0] = 1
+    img = torch.randn(B, 64, requires_grad=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    for layer in m.transformer.layers:
+        layer.self_attn.dropout = 0.0
+    m.train()
+    pooled = m(input_ids=ids, attention_mask=mask)
+    loss = crit(pooled, img)
+    loss.backward()
+    out = {"ids": ids, "mask": mask, "img": img.detach(), "pooled": pooled.detach(), "loss": loss.detach(),
+           "d_img": img.grad, "d_log_temp": crit.log_temp.grad, "log_temp": crit.log_temp.detach()}
+    for k, v in m.state_dict().items():
+        out["sd__" + k] = v
+    for k, v in m.named_parameters():
+        out["grad__" + k] = v.grad
+    npz("encoder_step.npz", **out)
+
+
 def collate_golden():
     from utils.collate_fn import skip_broken_collate_fn
     torch.manual_seed(400)
@@ -179,6 +212,7 @@ if __name__ == "__main__":
     lora_golden()
     loss_golden()
     text_encoder_golden()
+    encoder_step_golden()
     collate_golden()
     try:
         tokenizer_golden()
