@@ -284,6 +284,19 @@ int mi355_lora_pack(const long long* table, int n, void* stream);
 /* n records {src, dst, rows, cols, src_ld, dst_ld} (int64, device memory): dst[r][c] = src[r][c], fp32. */
 int mi355_copy2d_f32_batched(const long long* table, int n, void* stream);
 
+/* ---- data plane: read-only LMDB (dataset.py:173-183,213-216; the file format make_lmdb.py:39-75 writes) ------------
+ * Host code, no GPU.  liblmdb is not a dependency: the environment's data.mdb is mapped and its B+tree walked in place.
+ * open: `path` is the environment directory (with data.mdb) or the data file; NULL + mi355_last_error() on failure.
+ * entries: what `txn.stat()['entries']` returns (the data set's length is entries // 2, dataset.py:183).
+ * get: 0 = found (*data points into the map, valid until close, *size bytes), 1 = no such key (`txn.get` -> None),
+ * negative = damaged or unsupported file.  Safe to call from many threads (the map is read-only). */
+void* mi355_lmdb_open(const char* path);
+long long mi355_lmdb_entries(void* env);
+int mi355_lmdb_depth(void* env);
+int mi355_lmdb_page_size(void* env);
+int mi355_lmdb_get(void* env, const void* key, int klen, const void** data, long long* size);
+int mi355_lmdb_close(void* env);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,88 @@ def test_ddim_schedule_host_side():
     assert DDPMScheduler().config.num_train_timesteps == 1000
     x = torch.randn(2, 4, 4, 4)
     assert s.scale_model_input(x, 3) is x
+
+
+def _make_jpeg(seed, w=48, h=40):
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 255, (h // 8, w // 8, 3), dtype=np.uint8)
+    img = Image.fromarray(base, "RGB").resize((w, h), Image.BILINEAR)        # smooth content: JPEG keeps it recognisable
+    buf = io.BytesIO()
+    img.save(buf, format="JPEG", quality=95)
+    return buf.getvalue(), img
+
+
+def test_lmdb_reader_and_dataset(tmp_path):
+    """The data plane of dataset.py:169-229 on the library's LMDB page walker: a data base in liblmdb's file layout
+    (written by tests/lmdb_fixture.py: 1 200 samples = 2 400 keys, JPEG values on overflow pages, pickled metadata inline,
+    a three-level tree, the stale meta page first) is read back key by key, bit for bit; the dataset returns the
+    reference's sample dictionary; a corrupt image falls through to the next index; metadata that would import code is
+    refused.  (Format parity is unpinned: no file written by liblmdb itself exists here.)"""
+    import pickle
+    from lmdb_fixture import write_lmdb
+    from image_generator_amd import dataplane as dp
+    n = 1200
+    items, jpegs = {}, {}
+    for i in range(n):
+        ki, km = dp.lmdb_keys(i)
+        if i < 6:
+            jpegs[i] = _make_jpeg(i)
+            items[ki] = jpegs[i][0]
+        else:
+            items[ki] = bytes([i & 255]) * (3000 + 7 * i)                    # overflow values of many sizes
+        items[km] = pickle.dumps({"raw_text": f"tag_{i} blue_sky"})
+    items[dp.lmdb_keys(3)[0]] = b"not a jpeg" * 400                          # sample 3 does not decode
+    d = tmp_path / "db"
+    d.mkdir()
+    info = write_lmdb(str(d / "data.mdb"), items, txnid=7, fill=0.12)          # sparse pages: a deeper tree from few keys
+    assert info["depth"] >= 3 and info["overflow"] > n
+    env = dp.LMDBEnv(d)
+    assert env.entries == 2 * n
+    for k, v in items.items():
+        assert env.get(k) == v, k
+    assert env.get(b"image-99999999") is None and env.get(b"") is None and env.get(b"zzz") is None
+    env.close()
+    with pytest.raises(OSError):
+        dp.LMDBEnv(tmp_path / "missing")
+    (tmp_path / "junk").write_bytes(b"\0" * 8192)
+    with pytest.raises(OSError, match="not an LMDB"):
+        dp.LMDBEnv(tmp_path / "junk")
+
+    ds = dp.LMDBImageDataset(d, is_train=False)
+    assert len(ds) == n
+    s = ds[1]
+    assert set(s) == {"image", "text"} and s["text"] == {"raw_text": "tag_1 blue_sky"}
+    assert s["image"].shape == (3, 224, 224) and s["image"].dtype == torch.float32
+    want = torch.from_numpy(np.asarray(Image_open_rgb(jpegs[1][0]).resize((224, 224), 2), dtype=np.uint8).copy())
+    assert torch.equal(s["image"], (want.permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5)
+    assert ds[3]["text"]["raw_text"] == "tag_4 blue_sky"                      # corrupt image: the next sample stands in
+    tr = dp.LMDBImageDataset(d, is_train=True)
+    torch.manual_seed(0)
+    a = tr[2]["image"]
+    torch.manual_seed(0)
+    b = tr[2]["image"]
+    assert a.shape == (3, 512, 512) and torch.equal(a, b) and float(a.min()) >= -1 and float(a.max()) <= 1
+    flips = set()
+    for seed in range(8):
+        torch.manual_seed(seed)
+        flips.add(bool(torch.equal(tr[2]["image"], a)))
+    assert flips == {True, False}                                            # the flip / jitter draws do vary with the seed
+    # a DataLoader worker re-opens the map from the pickled dataset; the collate function is the reference's
+    import pickle as pk
+    ds2 = pk.loads(pk.dumps(ds))
+    batch = dp.skip_broken_collate_fn([ds2[0], None, ds2[1]])
+    assert batch["image"].shape == (2, 3, 224, 224) and batch["text"][1] == {"raw_text": "tag_1 blue_sky"}
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("executed",))
+    with pytest.raises(Exception, match="only plain"):
+        dp.load_metadata(pk.dumps({"raw_text": Evil()}))
+
+
+def Image_open_rgb(blob):
+    import io
+    from PIL import Image
+    return Image.open(io.BytesIO(blob)).convert("RGB")
