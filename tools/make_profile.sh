@@ -6,11 +6,11 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline "$@" > $out/bench.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extra "$@" > $out/bench.log 2>&1
 stats=$(find $out -name '*kernel_stats.csv' | head -1)
 trace=$(find $out -name '*kernel_trace.csv' | head -1)
 {
-  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline $*   (1 x MI355X)"
+  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extra $*   (1 x MI355X)"
   echo "# bench line of the same (profiled) run:"
   grep -o '{"metric.*' $out/bench.log
   echo

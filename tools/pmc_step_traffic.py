@@ -1,7 +1,9 @@
 """Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py --no-graph to per-family HBM-side bytes
 per launch and per step.  FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide reads at 64 bytes);
 WRITE_SIZE is taken as reported.  Both are in KiB.  usage: pmc_step_traffic.py <dir with FETCH_SIZE/ and WRITE_SIZE/>"""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 FAMS = [("gemm_conv", ("gemm_dma_kernel", "gemm_wide_kernel", "gemm_kernel", "splitk_reduce_kernel", "gemm_skinny_kernel")),
         ("wgrad", ("wgrad_",)), ("attention", ("attn_",)), ("adamw", ("adamw_kernel", "sumsq_")),
@@ -32,7 +34,10 @@ def load(d, counter):
 d = sys.argv[1]
 ft, fc, fs = load(d, "FETCH_SIZE")
 wt, wc, ws = load(d, "WRITE_SIZE")
-out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --no-graph --steps 2 --warmup 1 --prof-steps 0 --no-cpu-baseline",
+from bench import source_fingerprint          # noqa: E402  (bench.py only reads it back if it matches the running code)
+
+out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --no-graph --steps 2 --warmup 1 --prof-steps 0 --no-cpu-baseline --no-extra",
+       "source_fingerprint": source_fingerprint(),
        "steps_in_run": fs, "note": "bytes at the L2's memory side (Infinity-Cache hits included); fetch = 2 x FETCH_SIZE (gfx950 wide-read correction)",
        "families": {}}
 for fam in [f for f, _ in FAMS] + ["other"]:
