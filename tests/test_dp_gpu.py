@@ -2,17 +2,15 @@
 callbacks from the deferred weight-gradient queue, bf16 staging, and the optimizer reading the staged gradients."""
 import math
 import os
-import socket
 
 import pytest
 import torch
-import torch.distributed as dist
 
 pytestmark = pytest.mark.gpu
 D = "cuda:0"
 
 
-def test_dp_step_with_reducer_matches_plain_step():
+def test_dp_step_with_reducer_matches_plain_step(rccl_world1):
     from image_generator_amd.trainer import DenoiserTrainer
     from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
     g = torch.Generator().manual_seed(21)
@@ -37,11 +35,6 @@ def test_dp_step_with_reducer_matches_plain_step():
             norms.append(tr.opt.grad_norm())
         return losses, norms, tr
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(D))
     try:
         la, na, tr = run(True)
         # one more backward pass on each trainer from the same weights: the staged (bf16) gradients the optimizer
@@ -68,7 +61,7 @@ def test_dp_step_with_reducer_matches_plain_step():
         # reorder the fp32 additions
         assert float((st != st2).float().mean()) <= 0.05
     finally:
-        dist.destroy_process_group()
+        torch.cuda.synchronize()
     lb, nb, _ = run(False)
     assert la[0] == lb[0]                                    # same forward before any update
     for a, b in zip(la, lb):
@@ -78,7 +71,7 @@ def test_dp_step_with_reducer_matches_plain_step():
     assert la[-1] < la[0]
 
 
-def test_lora_dp_step_with_reducer_matches_plain_step():
+def test_lora_dp_step_with_reducer_matches_plain_step(rccl_world1):
     """LoRA fine-tune with the gradient reducer on (one rank over RCCL): the adapters are the reducer's only (tail)
     bucket, the frozen base has none, and the optimizer consumes the staged bf16 adapter gradients - the trajectory
     stays with the plain LoRA step's (bf16 rounding of the gradients only) and the base weights never move."""
@@ -116,17 +109,12 @@ def test_lora_dp_step_with_reducer_matches_plain_step():
                 assert torch.equal(p.detach(), base[n]), n
         return losses, norms, tr
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(D))
     try:
         la, na, tr = run(True)
         st, fg = tr.reducer.stage_all.float(), tr.opt.grad
         assert float(fg.norm()) > 0 and float((st - fg).norm() / fg.norm()) <= 2 ** -8
     finally:
-        dist.destroy_process_group()
+        torch.cuda.synchronize()
     lb, nb, _ = run(False)
     assert la[0] == lb[0]
     for a, b in zip(la, lb):
@@ -136,7 +124,7 @@ def test_lora_dp_step_with_reducer_matches_plain_step():
     assert la[-1] < la[0]
 
 
-def test_fullsize_direct_staging_matches_pack_pass():
+def test_fullsize_direct_staging_matches_pack_pass(rccl_world1):
     """SD-v1 denoiser at the benchmark size (batch 32, 32x32 latents) with the reducer on: the level-0 weight gradients
     are pixel-split there (fp32 atomics, packed afterwards), everything else is stored as bf16 by its own job.  The
     staged buffer equals, to bf16 rounding, the fp32 gradients of the same backward pass without direct staging, every
@@ -153,11 +141,6 @@ def test_fullsize_direct_staging_matches_pack_pass():
     ctx = torch.randn(B, T, 768, device=D, generator=g).to(torch.bfloat16)
     ts = torch.randint(0, 1000, (B,), device=D, generator=g)
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(D))
     try:
         out = []
         for direct in (True, False):
@@ -195,4 +178,4 @@ def test_fullsize_direct_staging_matches_pack_pass():
         # the fp32 buffer of the direct run holds only what no job staged
         assert float(fg_d.norm()) < float(fg_p.norm())
     finally:
-        dist.destroy_process_group()
+        torch.cuda.synchronize()
