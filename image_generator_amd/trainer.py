@@ -43,6 +43,52 @@ def cosine_warm_restarts_lr(base_lr, epoch_float, t0=10, t_mult=2, eta_min=1e-6)
     return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t_cur / t_i)) / 2
 
 
+class NativeComm:
+    """The library's own RCCL communicator (`mi355_dp_*`): all-reduces go straight onto the stream they are given, with
+    no hop through a process-group stream.  The unique id travels over the torch process group that `init_distributed`
+    made; one communicator per process, kept until exit."""
+
+    _instance = None
+
+    @classmethod
+    def get(cls, group=None):
+        if cls._instance is None:
+            cls._instance = cls(group)
+        return cls._instance
+
+    def __init__(self, group=None):
+        import ctypes
+        n = int(lib.mi355_dp_unique_id_bytes())
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        buf = ctypes.create_string_buffer(n)
+        if rank == 0:
+            check(lib.mi355_dp_unique_id(buf, n), "dp_unique_id")
+        box = [bytes(buf.raw) if rank == 0 else None]
+        if self.world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+        handle = ctypes.c_void_p()
+        check(lib.mi355_dp_comm_create(ctypes.byref(handle), box[0], n, rank, self.world), "dp_comm_create")
+        self.handle = handle
+        if int(lib.mi355_dp_comm_world(self.handle)) != self.world:
+            raise RuntimeError("NativeComm: RCCL reports another world size than the process group")
+
+    def all_reduce_sum(self, t):
+        """In place, on the current stream."""
+        if t.dtype not in (BF16, F32) or not t.is_contiguous():
+            raise ValueError("NativeComm.all_reduce_sum: contiguous bf16 or fp32 tensors only")
+        check(lib.mi355_dp_allreduce_sum(self.handle, t.data_ptr(), t.numel(), 0 if t.dtype == BF16 else 1, _stream()),
+              "dp_allreduce_sum")
+
+    def destroy(self):
+        if self.handle is not None:
+            torch.cuda.synchronize()
+            check(lib.mi355_dp_comm_destroy(self.handle), "dp_comm_destroy")
+            self.handle = None
+            type(self)._instance = None
+
+
 class GradBucketReducer:
     """Bucketed bf16 all-reduce of the flat fp32 gradient buffer, overlapped with backward.
 
@@ -53,10 +99,12 @@ class GradBucketReducer:
     makes the compute stream wait for all communication.
     """
 
-    def __init__(self, flat_grad, n_big, grad_packs, group=None, bucket_mb=64, unpack=False):
+    def __init__(self, flat_grad, n_big, grad_packs, group=None, bucket_mb=64, unpack=False, native=None):
         """flat_grad: fp32 gradient buffer; [0, n_big) holds the GEMM weights, the rest small parameters;
-        grad_packs: (offset, numel, pack) per layer, `pack.on_grad_ready` is installed here."""
+        grad_packs: (offset, numel, pack) per layer, `pack.on_grad_ready` is installed here;
+        native: a `NativeComm` to all-reduce through instead of the torch process group."""
         self.group = group
+        self.native = native
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.flat_grad = flat_grad
         self.device = self.flat_grad.device
@@ -136,7 +184,10 @@ class GradBucketReducer:
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 self._pack(start, end, layers)
-                dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
+                if self.native is not None:
+                    self.native.all_reduce_sum(stage)
+                else:
+                    dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
                 if self.unpack:
                     g.copy_(stage)                               # back to fp32 (the optimizer divides by world)
         else:
@@ -380,8 +431,11 @@ class DenoiserTrainer:
         self.reducer = None
         if self.world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1":
             n_big = 0 if self.opt.frozen_base else unet._n_big       # adapters only: one small tail bucket
+            # MI355_DP_NATIVE=1: all-reduce through the library's own communicator (enqueued on the reducer's stream
+            # directly) instead of the torch process group
+            native = NativeComm.get(group) if (os.environ.get("MI355_DP_NATIVE") == "1" and unet_on_gpu(unet)) else None
             self.reducer = GradBucketReducer(unet.enable_direct_grads(), n_big, unet._grad_packs, group=group,
-                                             bucket_mb=bucket_mb)
+                                             bucket_mb=bucket_mb, native=native)
         dev = self.opt.flat.device
         if alphas_cumprod is None:
             from .schedulers import sd_alphas_cumprod
@@ -583,6 +637,10 @@ class DenoiserTrainer:
         self._graph.replay()
         self.step_count += 1
         return self._static_loss
+
+
+def unet_on_gpu(unet):
+    return next(unet.parameters()).device.type == "cuda"
 
 
 def init_distributed():

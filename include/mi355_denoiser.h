@@ -297,6 +297,22 @@ int mi355_lmdb_page_size(void* env);
 int mi355_lmdb_get(void* env, const void* key, int klen, const void** data, long long* size);
 int mi355_lmdb_close(void* env);
 
+/* ---- data parallelism over RCCL (replaces DistributedDataParallel's gradient reducer: setup_training.py:39-41,
+ * trainer.py:74-77 - one process per device, gradients summed over the ranks while backward runs) ----------------------
+ * RCCL is bound when the first of these is called (the librccl.so.1 already in the process, else the system's): a
+ * single-GPU user never loads it.  Rank 0 makes a unique id (mi355_dp_unique_id_bytes() bytes of host memory) and hands it
+ * to the other ranks by any means it has; every rank then calls comm_create with its device current (collective: returns
+ * when all `world` ranks have joined).  allreduce_sum: in place over `count` elements at the device pointer `buf`, dtype
+ * 0 = bf16, 1 = fp32, asynchronous on `stream` with no hop through another stream; the ranks must issue their
+ * all-reduces in the same order.  comm_world returns the number of ranks RCCL reports.  One communicator per process;
+ * destroy it once, at exit, after the stream has drained. */
+int mi355_dp_unique_id_bytes(void);
+int mi355_dp_unique_id(void* out, int bytes);
+int mi355_dp_comm_create(void** comm, const void* unique_id, int bytes, int rank, int world);
+int mi355_dp_comm_world(void* comm);
+int mi355_dp_allreduce_sum(void* comm, void* buf, long long count, int dtype, void* stream);
+int mi355_dp_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

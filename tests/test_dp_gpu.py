@@ -179,3 +179,54 @@ def test_fullsize_direct_staging_matches_pack_pass(rccl_world1):
         assert float(fg_d.norm()) < float(fg_p.norm())
     finally:
         torch.cuda.synchronize()
+
+
+def test_native_communicator_and_trainer_through_it(rccl_world1):
+    """The library's own RCCL entry points (one rank): unique id -> communicator -> in-place bf16 / fp32 all-reduce on a
+    given stream (the sum over one rank is the input, bit for bit, and work queued on that stream before and after it
+    keeps its order), then the train step with the reducer all-reducing through that communicator: the same
+    trajectory, bit for bit, as through the torch process group (same kernels, same buffers, one rank)."""
+    import ctypes
+    from image_generator_amd._lib import lib, check
+    from image_generator_amd.trainer import DenoiserTrainer, NativeComm
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    assert lib.mi355_dp_unique_id_bytes() == 128
+    comm = NativeComm.get()
+    assert comm.world == 1 and lib.mi355_dp_comm_world(comm.handle) == 1
+    assert lib.mi355_dp_comm_world(None) < 0 and b"communicator" in lib.mi355_last_error()
+    side = torch.cuda.Stream(D)
+    for dt, code in ((torch.bfloat16, 0), (torch.float32, 1)):
+        x = torch.randn(1 << 20, device=D).to(dt)
+        want = (x.float() * 2 + 1).to(dt)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            x.mul_(2)
+            check(lib.mi355_dp_allreduce_sum(comm.handle, x.data_ptr(), x.numel(), code, side.cuda_stream), "allreduce")
+            x.add_(1)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(x, want)
+    assert lib.mi355_dp_allreduce_sum(comm.handle, x.data_ptr(), x.numel(), 5, side.cuda_stream) < 0     # unknown dtype
+
+    g = torch.Generator().manual_seed(29)
+    lat, noise = torch.randn(4, 4, 8, 8, generator=g).to(D), torch.randn(4, 4, 8, 8, generator=g).to(D)
+    ts, ctx = torch.randint(0, 1000, (4,), generator=g).to(D), torch.randn(4, 16, 64, generator=g).to(D).to(torch.bfloat16)
+
+    def run(native):
+        torch.manual_seed(0)
+        unet = UNet2DConditionModel(DenoiserConfig.small()).to(D)
+        os.environ["MI355_FORCE_REDUCER"] = "1"
+        if native:
+            os.environ["MI355_DP_NATIVE"] = "1"
+        try:
+            tr = DenoiserTrainer(unet, lr=1e-3, bucket_mb=0.25)
+        finally:
+            os.environ.pop("MI355_FORCE_REDUCER", None)
+            os.environ.pop("MI355_DP_NATIVE", None)
+        assert (tr.reducer.native is not None) == native
+        out = [float(tr.train_step(lat, noise, ts, ctx)) for _ in range(4)]
+        return out, tr.opt.flat.clone()
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    assert la == lb and torch.equal(pa, pb)
+    assert la[-1] < la[0]
