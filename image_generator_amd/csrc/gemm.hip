@@ -771,6 +771,239 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ping-pong variant for grids that fill the chip with 256 x 320 tiles (the 512^2 sampling step, the widest layers of
+// the train step): 8 waves as 2 (M) x 4 (N), each 128 x 80, ONE workgroup per CU.  The k-loop runs on 32-deep slabs in
+// a ring of four LDS buffers (36 fragment pieces = 36 KiB each, the piece layout of gemm_wide_kernel).  A slab is
+// multiplied in two phases (the wave's upper, then lower 64 rows: 20 MFMAs each); a phase is
+//     fragment reads + DMA requests -> s_barrier -> lgkmcnt(0) -> 20 MFMAs -> s_barrier.
+// The four waves of the lower tile half run ONE barrier behind the upper four, so while one wave of a SIMD multiplies,
+// its partner reads fragments and issues requests: neither the LDS reads nor the request bursts stop the matrix pipe.
+// Requests run three slabs ahead and are retired by a counted vmcnt (never 0 inside the loop):
+//     A pieces of slab n+3 are requested in the second phase of slab n, its B pieces in the first phase of slab n+1
+//     (two barriers after any wave last read that buffer, slab n-1's), and the second phase of slab n waits until
+//     slab n+1 has landed - one barrier before any wave reads it.
+// Waves 0-3 carry 5 pieces per slab (2 A + 3 B), waves 4-7 carry 4 (2 A + 2 B): the counts in the waits differ per half.
+// ---------------------------------------------------------------------------------------------
+template <int AMODE, int VAR = 0>
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 256, BN = 320, BK = 32, NW = 8;
+    constexpr int TM = 8, TN = 5;
+    constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16, PIECES = A_PIECES + B_PIECES;     // 16 + 20
+    constexpr int STAGE = PIECES * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int wm0 = wr * 128, wn0 = wc * 80;
+    const int grp = (VAR & 1) ? (wave & 1) : (VAR & 4) ? ((wave >> 1) & 1) : wr;      // which waves run one barrier behind
+
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % p.tiles_n;
+    const int tile_m = lid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nslab = p.K / BK;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw, 0, b_bytes, 0x00020000);
+
+    const int prow = lane >> 2;                                            // row inside the 16-row piece
+    const int kc = (lane & 3) ^ ((0x78 >> (2 * (lane >> 4))) & 3);         // k-chunk fetched by this lane
+    // A pieces of this wave: wave and wave + 8
+    int a_voff[2], a_iy0[2], a_ix0[2];
+    const int pad = p.g.pad;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int m = m0 + (wave + NW * q) * 16 + prow;
+        const bool ok = m < p.M;
+        a_iy0[q] = a_ix0[q] = 0;
+        if constexpr (amode_dense(AMODE)) {
+            a_voff[q] = ok ? (m * p.lda + kc * 8) * 2 : OOB_OFF;
+        } else {
+            const int mm = ok ? m : 0;
+            const int ox = mm % p.g.Wo;
+            const int t = mm / p.g.Wo;
+            const int oy = t % p.g.Ho;
+            const int b = t / p.g.Ho;
+            a_voff[q] = ok ? b * p.g.H * p.g.W : -1;
+            a_iy0[q] = oy * p.g.stride - pad;
+            a_ix0[q] = ox * p.g.stride - pad;
+        }
+    }
+    // B pieces of this wave: wave, wave + 8 and (waves 0-3) wave + 16
+    int b_voff[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int pc = wave + NW * q;
+        const int nl = pc * 16 + prow;
+        int n = n0 + nl;
+        if (p.geglu) {                       // first half of the tile: hidden rows, second half: the matching gate rows
+            const int F = p.N >> 1, f0 = tile_n * (BN / 2);
+            n = nl < BN / 2 ? f0 + nl : F + f0 + nl - BN / 2;
+            if (f0 + (nl < BN / 2 ? nl : nl - BN / 2) >= F) n = p.N;
+        }
+        b_voff[q] = (pc < B_PIECES && n < p.N) ? (n * p.ldb + kc * 8) * 2 : OOB_OFF;
+    }
+
+    // Plain 3x3 / 1x1 convolution (no up-sampling, no dilation): a piece's source address is affine in the tap, so the
+    // per-slab work is one add and one select per piece - `a_mask` holds which of the 9 taps fall inside the image.
+    // Slabs are requested in increasing order: the tap and the channel offset advance by increments, no division.
+    const bool conv_affine = !amode_dense(AMODE) && !p.g.ups && !p.g.dil;
+    int a_base[2] = {0, 0}, a_mask[2] = {0, 0};
+    if constexpr (!amode_dense(AMODE)) {
+        if (conv_affine) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a_base[q] = ((a_voff[q] + a_iy0[q] * p.g.W + a_ix0[q]) * p.g.C + kc * 8) * 2;
+                int mask = 0;
+                const int nt = p.g.ksize == 3 ? 3 : 1;
+                for (int ky = 0; ky < nt; ++ky)
+                    for (int kx = 0; kx < nt; ++kx) {
+                        const int sy = a_iy0[q] + ky, sx = a_ix0[q] + kx;
+                        if (a_voff[q] >= 0 && sy >= 0 && sx >= 0 && sy < p.g.H && sx < p.g.W) mask |= 1 << (ky * 3 + kx);
+                    }
+                a_mask[q] = mask;
+            }
+        }
+    }
+    int cur_c = 0, cur_ky = 0, cur_kx = 0;                   // of the next slab to be requested (conv only)
+    auto issue_a = [&](int slab) {
+        char* base = smem + (slab & 3) * STAGE;
+        int soffa = slab * (BK * 2), ky = 0, kx = 0;
+        if constexpr (!amode_dense(AMODE)) {
+            soffa = cur_c * 2;
+            ky = cur_ky; kx = cur_kx;
+        }
+        const int tap_off = (ky * p.g.W + kx) * p.g.C * 2, tap_bit = ky * 3 + kx;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int v = a_voff[q];
+            if constexpr (!amode_dense(AMODE)) {
+                if (conv_affine) {
+                    v = (a_mask[q] >> tap_bit) & 1 ? a_base[q] + tap_off : OOB_OFF;
+                } else {
+                    int sy = a_iy0[q] + ky, sx = a_ix0[q] + kx;
+                    bool ok = a_voff[q] >= 0 && sy >= 0 && sx >= 0;
+                    if (p.g.dil) {
+                        ok = ok && !((sy | sx) & 1);
+                        sy >>= 1; sx >>= 1;
+                    } else if (p.g.ups) {
+                        sy >>= 1; sx >>= 1;
+                    }
+                    ok = ok && sy < p.g.H && sx < p.g.W;
+                    v = ok ? ((a_voff[q] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
+                }
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + (wave + NW * q) * 1024), 16, v, soffa, 0, 0);
+        }
+        if constexpr (!amode_dense(AMODE)) {
+            cur_c += BK;
+            if (cur_c >= p.g.C) {
+                cur_c = 0;
+                if (++cur_kx == 3) { cur_kx = 0; ++cur_ky; }
+            }
+        }
+    };
+    auto issue_b = [&](int slab) {
+        char* base = smem + (slab & 3) * STAGE + A_PIECES * 1024;
+        const int soffb = slab * (BK * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base + wave * 1024), 16, b_voff[0], soffb, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base + (wave + NW) * 1024), 16, b_voff[1], soffb, 0, 0);
+        if (wave < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base + (wave + 2 * NW) * 1024), 16, b_voff[2], soffb, 0, 0);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rd = (fr * 4 + (fq ^ ((0x78 >> (2 * (fr >> 2))) & 3))) * 16;       // this lane's slot inside a fragment piece
+
+    // prologue: slabs 0, 1, 2 requested; slab 0 landed before the first read
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (d < nslab) { issue_a(d); issue_b(d); }
+    if (nslab >= 3) {
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (nslab == 2) {
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {                           // the second group runs one barrier behind
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (int n = 0; n < nslab; ++n) {
+        const char* st = smem + (n & 3) * STAGE;
+        const char* As = st + (wm0 >> 4) * 1024 + rd;
+        const char* Bs = st + (A_PIECES + wn0 / 16) * 1024 + rd;
+        bf16x8 af[4], bfr[TN];
+        // ---- first phase: rows 0-63 of the wave's tile
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *(const bf16x8*)(Bs + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + i * 1024);
+        if (n >= 1 && n + 2 < nslab) issue_b(n + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- second phase: rows 64-127
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + (4 + i) * 1024);
+        if (n + 3 < nslab) issue_a(n + 3);
+        // slab n + 1 landed: what may still be in flight is slab n + 2 and the A pieces of slab n + 3
+        if (n + 3 < nslab) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (n + 2 < nslab) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) {                           // every wave passes the same number of barriers
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_epilogue<BN, TM, TN, 512, BM, false>(p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // Skinny GEMM: out[M][W] = alpha * A[M][K] . Bw[W][K]^T with W = 8 or 16 (the rank-padded products of the LoRA
 // adapters: x A^T and dy B).  The tile kernels would spend a 128 x 64 tile, split-K slabs and a reduce launch on it;
 // here a workgroup owns 16 rows, its four waves take every fourth 32-deep k-step with both operands loaded straight
@@ -892,6 +1125,26 @@ static int launch_gemm_wide(const GemmArgs& a, unsigned a_bytes, unsigned b_byte
     return mi355_check_launch("gemm_wide_kernel");
 }
 
+template <int AMODE>
+static int launch_gemm_pp(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
+    constexpr int smem = 4 * 36 * 1024;       // four slabs; the epilogue re-uses them (64 staging rows of 324 floats)
+    static_assert(smem >= (64 * 324 + 16 * 320 + 64 * 16) * 4, "epilogue staging must fit");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    if (g_tune[2] == 1) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AMODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipLaunchKernelGGL((gemm_pp_kernel<AMODE, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, s, a, a_bytes, b_bytes);
+    } else if (g_tune[2] == 4) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AMODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipLaunchKernelGGL((gemm_pp_kernel<AMODE, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, s, a, a_bytes, b_bytes);
+    } else
+    hipLaunchKernelGGL((gemm_pp_kernel<AMODE>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, s, a, a_bytes, b_bytes);
+    return mi355_check_launch("gemm_pp_kernel");
+}
+
 // Split-K choice by a small cost model (all in microseconds): the grid runs in waves of `capacity`
 // co-resident workgroups (2 per CU); a workgroup spends ~t_tile per 64-deep k-tile; splitting adds the
 // slab write + reduce pass.  Picks the split with the smallest estimated makespan.
@@ -1003,7 +1256,27 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
             a.tiles_m = (a.M + 255) / 256;
         }
     }
-    if (dma_ok && a.bm == 256) {
+    // 256 x 320 ping-pong tiles when they fill the 256 CUs in whole rounds (one workgroup per CU)
+    bool use_pp = false;
+    {
+        static const int pp_on = getenv("MI355_GEMM_PP") ? atoi(getenv("MI355_GEMM_PP")) : 1;
+        static const int pp_fill = getenv("MI355_GEMM_PP_FILL") ? atoi(getenv("MI355_GEMM_PP_FILL")) : 80;    // percent
+        const int tn = a.geglu ? (a.N / 2 + 159) / 160 : a.N / 320;
+        const int tpp = ((a.M + 255) / 256) * tn;
+        const int rounds = (tpp + 255) / 256;
+        if (pp_on && g_tune[1] == 0 && dma_ok && sk == 1 && amode != AMODE_DENSE_LORA && a.K % 32 == 0 && a.K >= 128 &&
+            (a.K >= 512 || tpp >= 1024 || g_tune[3]) &&      // short loops: one workgroup per CU cannot hide its epilogue
+            (a.geglu ? (a.N / 2) % 160 == 0 : a.N % 320 == 0) && tpp * 100 >= rounds * 256 * pp_fill) {
+            use_pp = true;
+            a.bm = 256;
+            a.tiles_m = (a.M + 255) / 256;
+            a.tiles_n = tn;
+        }
+    }
+    if (use_pp) {
+        const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
+        rc = amode == AMODE_DENSE ? launch_gemm_pp<AMODE_DENSE>(a, ab, bb, s) : launch_gemm_pp<AMODE_CONV_FAST>(a, ab, bb, s);
+    } else if (dma_ok && a.bm == 256) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
         rc = amode == AMODE_DENSE ? launch_gemm_wide<AMODE_DENSE>(a, ab, bb, s)
              : amode == AMODE_DENSE_LORA ? launch_gemm_wide<AMODE_DENSE_LORA>(a, ab, bb, s)

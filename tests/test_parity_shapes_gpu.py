@@ -374,3 +374,65 @@ def test_integer_rows_hold_on_the_gpu_box_too(golden_dir):
     h.test_dataplane_indexing_bit_exact(golden_dir)
     h.test_lr_schedule_matches_torch(golden_dir)
     h.test_ddim_schedule_host_side()
+
+
+@pytest.mark.parametrize("case", ["dense", "dense_ragged", "conv", "conv_ups", "geglu", "short_k"])
+def test_pingpong_tile_kernel_against_fp32(case):
+    """The 256 x 320 ping-pong kernel (grids that fill the chip in whole rounds: the 512^2 sampling step's layers) against
+    the same contraction in fp32 on the device: dense with bias / row bias / residual, a ragged last row tile,
+    3x3 convolution (zero padding through out-of-range DMA offsets, several taps per tile column), nearest-2x
+    up-sampling convolution, fused GEGLU, and the shortest loop it accepts (4 slabs: prologue and tail only).
+    Per element |err| <= 2^-7 |ref| + 2e-2 (bf16 output rounding 2^-9, fp32 accumulation), and the kernel the library
+    picks instead when this one is switched off gives the same bits."""
+    from image_generator_amd import ops
+    from image_generator_amd._lib import lib
+    torch.manual_seed(5)
+
+    def close(got, ref):
+        got, ref = got.float(), ref.float()
+        bad = (got - ref).abs() > 2 ** -7 * ref.abs() + 2e-2
+        assert not bool(bad.any()), (case, int(bad.sum()), float((got - ref).abs().max()))
+
+    if case in ("dense", "dense_ragged", "short_k"):
+        M = 65536 - (100 if case == "dense_ragged" else 0)
+        K = 128 if case == "short_k" else 448
+        N = 320
+        x = torch.randn(M, K, device=D).to(BF)
+        w = (torch.randn(N, K, device=D) * K ** -0.5).to(BF)
+        bias = torch.randn(N, device=D)
+        rowbias = torch.randn(M // 1024 + 1, N, device=D)
+        res = torch.randn(M, N, device=D).to(BF)
+        fn = lambda: ops.gemm(x, w, bias=bias, rowbias=rowbias, rowbias_div=1024, residual=res)
+        ref = x.float() @ w.float().t() + bias + rowbias[torch.arange(M, device=D) // 1024] + res.float()
+    elif case in ("conv", "conv_ups"):
+        ups = case == "conv_ups"
+        B, H, C, Co = 16, (32 if ups else 64), 128, 320
+        x = torch.randn(B, H, H, C, device=D).to(BF)
+        w = (torch.randn(Co, 3, 3, C, device=D) * (9 * C) ** -0.5).to(BF)
+        bias = torch.randn(Co, device=D)
+        fn = lambda: ops.conv2d(x, w, Co, 3, ups=ups, bias=bias)
+        xin = x.float().permute(0, 3, 1, 2)
+        if ups:
+            xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
+        ref = torch.nn.functional.conv2d(xin, w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    else:
+        M, K, F = 65536, 320, 320
+        x = torch.randn(M, K, device=D).to(BF)
+        w = (torch.randn(2 * F, K, device=D) * K ** -0.5).to(BF)
+        bias = torch.randn(2 * F, device=D)
+        fn = lambda: ops.gemm_geglu(x, w, bias)
+        y = x.float() @ w.float().t() + bias
+        ref = y[:, :F] * torch.nn.functional.gelu(y[:, F:])
+    lib.mi355_tune_set(1, 0)
+    lib.mi355_tune_set(3, 1)              # also for loops shorter than the launcher would give it
+    try:
+        got = fn()
+        lib.mi355_tune_set(1, 1)
+        other = fn()
+    finally:
+        lib.mi355_tune_set(1, 0)
+        lib.mi355_tune_set(3, 0)
+    close(got, ref)
+    close(other, ref)
+    # both kernels add their 32-deep MFMA steps in increasing k, so the two results are expected to agree bit for bit
+    assert torch.equal(got, other)
