@@ -541,6 +541,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     }
     const int nbp = (B_PIECES - wave + NW - 1) / NW;     // B pieces of this wave (uneven when NW does not divide them)
 
+    // Plain 3x3 / 1x1 convolution (no up-sampling, no dilation): a piece's source address is affine in the tap, so a
+    // request costs one add and one select per piece (`a_mask`: which of the 9 taps fall inside the image).  Tiles are
+    // requested in increasing order: the tap and the channel offset advance by increments, no division per tile.
+    const bool conv_affine = !amode_dense(AMODE) && !p.g.ups && !p.g.dil;
+    int a_base[A_P], a_mask[A_P];
+    int cur_c = 0, cur_ky = 0, cur_kx = 0;
+    if constexpr (!amode_dense(AMODE)) {
+#pragma unroll
+        for (int j = 0; j < A_P; ++j) {
+            a_base[j] = ((a_voff[j] + a_iy0[j] * p.g.W + a_ix0[j]) * p.g.C + kc * 8) * 2;
+            int mask = 0;
+            if (conv_affine) {
+                const int nt = p.g.ksize == 3 ? 3 : 1;
+                for (int ky = 0; ky < nt; ++ky)
+                    for (int kx = 0; kx < nt; ++kx) {
+                        const int sy = a_iy0[j] + ky, sx = a_ix0[j] + kx;
+                        if (a_voff[j] >= 0 && sy >= 0 && sx >= 0 && sy < p.g.H && sx < p.g.W) mask |= 1 << (ky * 3 + kx);
+                    }
+            }
+            a_mask[j] = mask;
+        }
+        const int kk = kt_begin * BK;
+        const int tap = kk / p.g.C;
+        cur_c = kk - tap * p.g.C;
+        if (p.g.ksize == 3) { cur_ky = tap / 3; cur_kx = tap - cur_ky * 3; }
+    }
+
     auto issue = [&](int kt, int stage) {
         char* As = smem + stage * STAGE;
         char* Bs = As + BM * 128;
@@ -550,24 +577,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
             for (int j = 0; j < A_P; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + NW * j) * 1024), 16, a_voff[j], soff, 0, 0);
         } else {
-            const int kk = kt * BK;
-            const int tap = kk / p.g.C;
-            const int soff = (kk - tap * p.g.C) * 2;
-            int ky = 0, kx = 0;
-            if (p.g.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
+            const int soff = cur_c * 2;
+            const int ky = cur_ky, kx = cur_kx;
+            const int tap_off = (ky * p.g.W + kx) * p.g.C * 2, tap_bit = ky * 3 + kx;
 #pragma unroll
             for (int j = 0; j < A_P; ++j) {
-                int sy = a_iy0[j] + ky, sx = a_ix0[j] + kx;
-                bool ok = a_voff[j] >= 0 && sy >= 0 && sx >= 0;
-                if (p.g.dil) {
-                    ok = ok && !((sy | sx) & 1);
-                    sy >>= 1; sx >>= 1;
-                } else if (p.g.ups) {
-                    sy >>= 1; sx >>= 1;
+                int voff;
+                if (conv_affine) {
+                    voff = (a_mask[j] >> tap_bit) & 1 ? a_base[j] + tap_off : OOB_OFF;
+                } else {
+                    int sy = a_iy0[j] + ky, sx = a_ix0[j] + kx;
+                    bool ok = a_voff[j] >= 0 && sy >= 0 && sx >= 0;
+                    if (p.g.dil) {
+                        ok = ok && !((sy | sx) & 1);
+                        sy >>= 1; sx >>= 1;
+                    } else if (p.g.ups) {
+                        sy >>= 1; sx >>= 1;
+                    }
+                    ok = ok && sy < p.g.H && sx < p.g.W;
+                    voff = ok ? ((a_voff[j] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
                 }
-                ok = ok && sy < p.g.H && sx < p.g.W;
-                const int voff = ok ? ((a_voff[j] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + NW * j) * 1024), 16, voff, soff, 0, 0);
+            }
+            cur_c += BK;
+            if (cur_c >= p.g.C) {
+                cur_c = 0;
+                if (++cur_kx == 3) { cur_kx = 0; ++cur_ky; }
             }
         }
         const int soffb = kt * (BK * 2);
@@ -700,16 +735,37 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
         }
     }
 
+    // plain convolutions: affine per-tap addresses and an inside-the-image mask per piece, taps advanced by increments
+    // (tiles are requested in increasing order) - see gemm_dma_kernel
+    const bool conv_affine = !amode_dense(AMODE) && !p.g.ups && !p.g.dil;
+    int a_base[NP], a_mask[NP];
+    int cur_c = 0, cur_ky = 0, cur_kx = 0;
+    if constexpr (!amode_dense(AMODE)) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            a_base[q] = ((voff[q] + iy0[q] * p.g.W + ix0[q]) * p.g.C + kc * 8) * 2;
+            int mask = 0;
+            if (conv_affine && wave + NW * q < A_PIECES) {
+                const int nt = p.g.ksize == 3 ? 3 : 1;
+                for (int ky = 0; ky < nt; ++ky)
+                    for (int kx = 0; kx < nt; ++kx) {
+                        const int sy = iy0[q] + ky, sx = ix0[q] + kx;
+                        if (voff[q] >= 0 && sy >= 0 && sx >= 0 && sy < p.g.H && sx < p.g.W) mask |= 1 << (ky * 3 + kx);
+                    }
+            }
+            a_mask[q] = mask;
+        }
+    }
+
     auto issue = [&](int kt, int stage) {
         char* base = smem + stage * STAGE;
         const int soffb = kt * (BK * 2);
         int soffa = soffb, ky = 0, kx = 0;
         if constexpr (!amode_dense(AMODE)) {
-            const int kk = kt * BK;
-            const int tap = kk / p.g.C;
-            soffa = (kk - tap * p.g.C) * 2;
-            if (p.g.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
+            soffa = cur_c * 2;
+            ky = cur_ky; kx = cur_kx;
         }
+        const int tap_off = (ky * p.g.W + kx) * p.g.C * 2, tap_bit = ky * 3 + kx;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int pc = wave + NW * q;
@@ -717,20 +773,31 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
             if (pc < A_PIECES) {
                 int v = voff[q];
                 if constexpr (!amode_dense(AMODE)) {
-                    int sy = iy0[q] + ky, sx = ix0[q] + kx;
-                    bool ok = voff[q] >= 0 && sy >= 0 && sx >= 0;
-                    if (p.g.dil) {
-                        ok = ok && !((sy | sx) & 1);
-                        sy >>= 1; sx >>= 1;
-                    } else if (p.g.ups) {
-                        sy >>= 1; sx >>= 1;
+                    if (conv_affine) {
+                        v = (a_mask[q] >> tap_bit) & 1 ? a_base[q] + tap_off : OOB_OFF;
+                    } else {
+                        int sy = iy0[q] + ky, sx = ix0[q] + kx;
+                        bool ok = voff[q] >= 0 && sy >= 0 && sx >= 0;
+                        if (p.g.dil) {
+                            ok = ok && !((sy | sx) & 1);
+                            sy >>= 1; sx >>= 1;
+                        } else if (p.g.ups) {
+                            sy >>= 1; sx >>= 1;
+                        }
+                        ok = ok && sy < p.g.H && sx < p.g.W;
+                        v = ok ? ((voff[q] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
                     }
-                    ok = ok && sy < p.g.H && sx < p.g.W;
-                    v = ok ? ((voff[q] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + pc * 1024), 16, v, soffa, 0, 0);
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base + pc * 1024), 16, voff[q], soffb, 0, 0);
+            }
+        }
+        if constexpr (!amode_dense(AMODE)) {
+            cur_c += BK;
+            if (cur_c >= p.g.C) {
+                cur_c = 0;
+                if (++cur_kx == 3) { cur_kx = 0; ++cur_ky; }
             }
         }
     };
