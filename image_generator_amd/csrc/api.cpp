@@ -6,6 +6,7 @@
 #include <vector>
 
 static thread_local char g_err[512] = "";
+int mi355_g_tune[16];
 
 int mi355_fail(int code, const char* fmt, ...) {
     va_list ap;

@@ -17,6 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MI355_ERR_UNSUPPORTED (-3)
 
 // Records a message retrievable through mi355_last_error() (thread-local) and returns `code`.
+// run-time tuning switches of the launchers (mi355_tune_set; measurement aid, all zero by default)
+extern int mi355_g_tune[16];
 int mi355_fail(int code, const char* fmt, ...);
 // Checks hipGetLastError() after a launch.
 int mi355_check_launch(const char* what);

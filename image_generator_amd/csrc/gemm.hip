@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 
 // Tuning switches settable at run time (A/B measurements of kernel variants inside one process): mi355_tune_set().
 // No key is read by the committed launchers; an experiment reads g_tune[key] where it picks its variant.
-static int g_tune[16];
+#define g_tune mi355_g_tune
 
 template <int BN, int AMODE>
 static int launch_gemm(const GemmArgs& a, hipStream_t s) {
