@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
 //     slab n+1 has landed - one barrier before any wave reads it.
 // Waves 0-3 carry 5 pieces per slab (2 A + 3 B), waves 4-7 carry 4 (2 A + 2 B): the counts in the waits differ per half.
 // ---------------------------------------------------------------------------------------------
-template <int AMODE, int VAR = 0>
+template <int AMODE>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 256, BN = 320, BK = 32, NW = 8;
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsig
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int wm0 = wr * 128, wn0 = wc * 80;
-    const int grp = (VAR & 1) ? (wave & 1) : (VAR & 4) ? ((wave >> 1) & 1) : wr;      // which waves run one barrier behind
+    const int grp = wr;       // waves w and w + 4 share a SIMD: grouping by wave parity measured 11-19 % slower
 
     int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lid % p.tiles_n;
@@ -1201,13 +1201,6 @@ static int launch_gemm_pp(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes,
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    if (g_tune[2] == 1) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AMODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipLaunchKernelGGL((gemm_pp_kernel<AMODE, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, s, a, a_bytes, b_bytes);
-    } else if (g_tune[2] == 4) {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AMODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipLaunchKernelGGL((gemm_pp_kernel<AMODE, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, s, a, a_bytes, b_bytes);
-    } else
     hipLaunchKernelGGL((gemm_pp_kernel<AMODE>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, s, a, a_bytes, b_bytes);
     return mi355_check_launch("gemm_pp_kernel");
 }
