@@ -320,7 +320,7 @@ def main():
                                    "WRITE_SIZE, bytes per call)")
                 else:
                     traffic_src = "none: the committed counter profile was collected from other kernel sources"
-            roof = {"bound": "mfma", "kernel": "gemm_dma_kernel family (implicit-GEMM conv + linear, fwd and dgrad)",
+            roof = {"bound": "mfma", "kernel": "gemm_dma / gemm_pp / gemm_wide kernel family (implicit-GEMM conv + linear, fwd and dgrad)",
                     "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "event_pair_overhead_us": pair_us,
                     "measured_on_this_device": measured,

@@ -4,7 +4,7 @@ utilisation of every contraction-kernel family of the train step: MFMA-busy cycl
 usage: pmc_step_mfma.py <dir with the pass's csv>"""
 import csv, glob, json, sys, collections
 
-FAMS = [("gemm_conv (fwd + dgrad)", ("gemm_dma_kernel", "gemm_wide_kernel", "gemm_kernel", "gemm_skinny_kernel")),
+FAMS = [("gemm_conv (fwd + dgrad)", ("gemm_dma_kernel", "gemm_wide_kernel", "gemm_pp_kernel", "gemm_kernel", "gemm_skinny_kernel")),
         ("wgrad (grouped)", ("wgrad_",)), ("attention fwd", ("attn_fwd",)), ("attention bwd", ("attn_bwd",))]
 
 

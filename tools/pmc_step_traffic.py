@@ -5,7 +5,7 @@ import csv, glob, json, os, sys, collections
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-FAMS = [("gemm_conv", ("gemm_dma_kernel", "gemm_wide_kernel", "gemm_kernel", "splitk_reduce_kernel", "gemm_skinny_kernel")),
+FAMS = [("gemm_conv", ("gemm_dma_kernel", "gemm_wide_kernel", "gemm_pp_kernel", "gemm_kernel", "splitk_reduce_kernel", "gemm_skinny_kernel")),
         ("wgrad", ("wgrad_",)), ("attention", ("attn_",)), ("adamw", ("adamw_kernel", "sumsq_")),
         ("norm", ("gn_", "ln_", "reduce_rows")), ]
 
