@@ -14,6 +14,7 @@
 // The epilogue stages fp32 accumulators through LDS so that bias / broadcast row bias (timestep
 // embedding) / LoRA rank-r update / residual are applied with 16-byte coalesced accesses.
 #include "common.h"
+#include <mutex>
 #include <stdlib.h>
 
 struct ConvGeom {
@@ -1168,11 +1169,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 template <int BN, int AMODE>
 static int launch_gemm(const GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (128 + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [] {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    });
     const int grid = a.tiles_m * a.tiles_n * a.splitk;
     hipLaunchKernelGGL((gemm_kernel<BN, AMODE>), dim3(grid), dim3(256), smem, s, a);
     return mi355_check_launch("gemm_kernel");
@@ -1183,11 +1183,10 @@ static int launch_gemm_wide(const GemmArgs& a, unsigned a_bytes, unsigned b_byte
     // two 26 KiB stages; the epilogue re-uses them for 64 staging rows + low-rank factors + low-rank activations
     constexpr int smem = (64 * 164 + 16 * 160 + 64 * 16) * 4;
     static_assert(smem >= 2 * 26 * 1024, "stages must fit");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [] {
         (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL((gemm_wide_kernel<AMODE>), dim3(a.tiles_m * a.tiles_n), dim3(256), smem, s, a, a_bytes, b_bytes);
     return mi355_check_launch("gemm_wide_kernel");
 }
@@ -1196,11 +1195,10 @@ template <int AMODE>
 static int launch_gemm_pp(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
     constexpr int smem = 4 * 36 * 1024;       // four slabs; the epilogue re-uses them (64 staging rows of 324 floats)
     static_assert(smem >= (64 * 324 + 16 * 320 + 64 * 16) * 4, "epilogue staging must fit");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [] {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL((gemm_pp_kernel<AMODE>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, s, a, a_bytes, b_bytes);
     return mi355_check_launch("gemm_pp_kernel");
 }
@@ -1211,11 +1209,10 @@ static int launch_gemm_pp(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes,
 template <int BN, int AMODE>
 static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
     constexpr int smem = 2 * (128 + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [] {
         (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    });
     const int grid = a.tiles_m * a.tiles_n * a.splitk;
     // measured on the denoiser step: 8 waves win up to two workgroups per CU, 4 waves beyond
     static const int nw8_max = getenv("MI355_GEMM_NW8") ? atoi(getenv("MI355_GEMM_NW8")) : 512;
@@ -1224,20 +1221,18 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
     static const int nst3_max = getenv("MI355_GEMM_NST3") ? atoi(getenv("MI355_GEMM_NST3")) : 256;
     if (grid <= nst3_max && grid <= nw8_max) {
         constexpr int smem3 = 3 * (128 + BN) * 128;
-        static bool attr83_set = false;
-        if (!attr83_set) {
+        static std::once_flag attr83_set;
+        std::call_once(attr83_set, [] {
             (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
-            attr83_set = true;
-        }
+        });
         hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8, 128, 3>), dim3(grid), dim3(512), smem3, s, a, a_bytes, b_bytes);
         return mi355_check_launch("gemm_dma_kernel<8 waves, 3 stages>");
     }
     if (grid <= nw8_max) {
-        static bool attr8_set = false;
-        if (!attr8_set) {
+        static std::once_flag attr8_set;
+        std::call_once(attr8_set, [] {
             (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr8_set = true;
-        }
+        });
         hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8>), dim3(grid), dim3(512), smem, s, a, a_bytes, b_bytes);
         return mi355_check_launch("gemm_dma_kernel<8 waves>");
     }

@@ -682,12 +682,11 @@ int mi355_layernorm_bwd(const void* x, const void* dy, const float* stats, const
     do {                                                                                                       \
         constexpr int threads = NCH <= 2 ? 1024 : 512;                                                         \
         const size_t sh = ((size_t)(threads / 64) * 2 + 1) * C * sizeof(float);                                \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
+        static std::once_flag attr_set;                                                                          \
+        std::call_once(attr_set, [] {                                                                                       \
             (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                (int)(((size_t)(threads / 64) * 2 + 1) * 512 * NCH * sizeof(float)));          \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
+                                (int)(((size_t)(threads / 64) * 2 + 1) * 512 * NCH * sizeof(float)));                                                                                   \
+        });                                                                                                      \
         hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(grid), dim3(threads), sh, st, (const bf16_t*)x,            \
                            (const bf16_t*)dy, stats, gamma, (bf16_t*)dx, scratch, M, C, (const bf16_t*)dres); \
     } while (0)

@@ -19,7 +19,12 @@
  *   - `stream` is a hipStream_t; all work is enqueued asynchronously on it, no call synchronises;
  *   - return value 0 = ok, negative = error (MI355_ERR_*); mi355_last_error() gives the message
  *     (thread local).  No C++ exception crosses this boundary;
- *   - "workspace"/"scratch" arguments are caller-provided device buffers of the documented size.
+ *   - "workspace"/"scratch" arguments are caller-provided device buffers of the documented size;
+ *   - threads: the compute entry points keep no mutable state between calls (one-time kernel attributes are set under
+ *     std::call_once) and may be called concurrently from several host threads, e.g. autograd's backward threads, each
+ *     with its own stream and buffers.  Exceptions, each documented at its declaration: mi355_groupnorm_fwd_static (one
+ *     scratch array per GPU), the mi355_prof_* measurement calls (one process-wide record list, mutex-guarded),
+ *     mi355_tune_set (process-wide switches for A/B measurements; not for use while other threads launch).
  */
 #ifndef MI355_DENOISER_H
 #define MI355_DENOISER_H
