@@ -376,12 +376,12 @@ def test_integer_rows_hold_on_the_gpu_box_too(golden_dir):
     h.test_ddim_schedule_host_side()
 
 
-@pytest.mark.parametrize("case", ["dense", "dense_ragged", "conv", "conv_ups", "geglu", "short_k"])
+@pytest.mark.parametrize("case", ["dense", "dense_ragged", "conv", "conv_ups", "conv_dil", "conv_s2", "geglu", "short_k"])
 def test_pingpong_tile_kernel_against_fp32(case):
     """The 256 x 320 ping-pong kernel (grids that fill the chip in whole rounds: the 512^2 sampling step's layers) against
     the same contraction in fp32 on the device: dense with bias / row bias / residual, a ragged last row tile,
     3x3 convolution (zero padding through out-of-range DMA offsets, several taps per tile column), nearest-2x
-    up-sampling convolution, fused GEGLU, and the shortest loop it accepts (4 slabs: prologue and tail only).
+    up-sampling, zero-dilated (the data gradient of a stride-2 convolution) and stride-2 convolutions, fused GEGLU, and the shortest loop it accepts (4 slabs: prologue and tail only).
     Per element |err| <= 2^-7 |ref| + 2e-2 (bf16 output rounding 2^-9, fp32 accumulation), and the kernel the library
     picks instead when this one is switched off gives the same bits."""
     from image_generator_amd import ops
@@ -404,17 +404,25 @@ def test_pingpong_tile_kernel_against_fp32(case):
         res = torch.randn(M, N, device=D).to(BF)
         fn = lambda: ops.gemm(x, w, bias=bias, rowbias=rowbias, rowbias_div=1024, residual=res)
         ref = x.float() @ w.float().t() + bias + rowbias[torch.arange(M, device=D) // 1024] + res.float()
-    elif case in ("conv", "conv_ups"):
-        ups = case == "conv_ups"
-        B, H, C, Co = 16, (32 if ups else 64), 128, 320
+    elif case.startswith("conv"):
+        ups, dil, s2 = case == "conv_ups", case == "conv_dil", case == "conv_s2"
+        B, H, C, Co = 16, (128 if s2 else 32 if (ups or dil) else 64), 128, 320          # 64 x 64 outputs in every case
         x = torch.randn(B, H, H, C, device=D).to(BF)
         w = (torch.randn(Co, 3, 3, C, device=D) * (9 * C) ** -0.5).to(BF)
         bias = torch.randn(Co, device=D)
-        fn = lambda: ops.conv2d(x, w, Co, 3, ups=ups, bias=bias)
+        if dil:
+            fn = lambda: ops.conv2d(x, w, Co, 3, dil=True, out_hw=(64, 64), bias=bias)
+        else:
+            fn = lambda: ops.conv2d(x, w, Co, 3, stride=2 if s2 else 1, ups=ups, bias=bias)
         xin = x.float().permute(0, 3, 1, 2)
         if ups:
             xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
-        ref = torch.nn.functional.conv2d(xin, w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+        if dil:
+            xd = torch.zeros(B, C, 64, 64, device=D)
+            xd[:, :, ::2, ::2] = xin
+            xin = xd
+        ref = torch.nn.functional.conv2d(xin, w.float().permute(0, 3, 1, 2), bias, stride=2 if s2 else 1,
+                                         padding=1).permute(0, 2, 3, 1)
     else:
         M, K, F = 65536, 320, 320
         x = torch.randn(M, K, device=D).to(BF)
