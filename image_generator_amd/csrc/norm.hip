@@ -25,10 +25,13 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 // gpart [B][strips][G][2]: per-group sums of this strip (MODE 1: weighted by gamma).
 // cpart [B][strips][2][C]: per-channel sums (MODE 1 only; feeds dbeta / dgamma).
 template <int MODE>
+// x2 (optional, MODE 0): the input is the channel concatenation [x | x2] of two tensors, x holding the first C1 channels
+// (rows of C1) and x2 the other C - C1 (rows of C - C1): the concatenated tensor is never materialised.
 __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                   const float* __restrict__ stats, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float* __restrict__ gpart, float* __restrict__ cpart,
-                                  int HW, int C, int G, int rows_per_block, int silu) {
+                                  int HW, int C, int G, int rows_per_block, int silu,
+                                  const bf16_t* __restrict__ x2 = nullptr, int C1 = 0) {
     const int nc = C >> 3;
     const int b = blockIdx.y;
     const int c8 = threadIdx.x % nc, rp = threadIdx.x / nc, rpar = blockDim.x / nc;
@@ -49,6 +52,13 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
     }
     float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const size_t base = (size_t)b * HW * C + c8 * 8;
+    // this thread's chunk of every row: xs + (b * HW + r) * ldx
+    int ldx = C;
+    const bf16_t* xs = x + c8 * 8;
+    if (x2 != nullptr) {
+        if (c8 * 8 < C1) { ldx = C1; } else { xs = x2 + (c8 * 8 - C1); ldx = C - C1; }
+    }
+    xs += (size_t)b * HW * ldx;
     // four rows in flight per thread: the loads of a row are otherwise exposed in full on every iteration
     auto accumulate = [&](const bf16x8& xv, const bf16x8& dv) {
         if (MODE == 0) {
@@ -69,14 +79,14 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
         bf16x8 xv[4], dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            xv[u] = *(const bf16x8*)(x + base + (size_t)(r + u * rpar) * C);
+            xv[u] = *(const bf16x8*)(xs + (size_t)(r + u * rpar) * ldx);
             if (MODE == 1) dv[u] = *(const bf16x8*)(dy + base + (size_t)(r + u * rpar) * C);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) accumulate(xv[u], dv[u]);
     }
     for (; r < r_end; r += rpar) {
-        const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)r * C);
+        const bf16x8 xv = *(const bf16x8*)(xs + (size_t)r * ldx);
         bf16x8 dv = xv;
         if (MODE == 1) dv = *(const bf16x8*)(dy + base + (size_t)r * C);
         accumulate(xv, dv);
@@ -129,7 +139,8 @@ __device__ __forceinline__ void gn_group_sums(const float* __restrict__ gpart, f
 
 __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gpart, float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                bf16_t* __restrict__ y, int HW, int C, int G, int rows_per_block, int silu, float eps) {
+                                bf16_t* __restrict__ y, int HW, int C, int G, int rows_per_block, int silu, float eps,
+                                const bf16_t* __restrict__ x2 = nullptr, int C1 = 0) {
     extern __shared__ float gs[];            // [G][2] -> mean, rstd
     const int nc = C >> 3;
     const int b = blockIdx.y;
@@ -161,6 +172,12 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
     int r_end = r_begin + rows_per_block;
     if (r_end > HW) r_end = HW;
     const size_t base = (size_t)b * HW * C + c8 * 8;
+    int ldx = C;                             // two-source input: see gn_partial_kernel
+    const bf16_t* xs = x + c8 * 8;
+    if (x2 != nullptr) {
+        if (c8 * 8 < C1) { ldx = C1; } else { xs = x2 + (c8 * 8 - C1); ldx = C - C1; }
+    }
+    xs += (size_t)b * HW * ldx;
     auto apply = [&](const bf16x8& xv, int r) {
         bf16x8 ov;
 #pragma unroll
@@ -175,11 +192,11 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
     for (; r + 3 * rpar < r_end; r += 4 * rpar) {
         bf16x8 xv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xv[u] = *(const bf16x8*)(x + base + (size_t)(r + u * rpar) * C);
+        for (int u = 0; u < 4; ++u) xv[u] = *(const bf16x8*)(xs + (size_t)(r + u * rpar) * ldx);
 #pragma unroll
         for (int u = 0; u < 4; ++u) apply(xv[u], r + u * rpar);
     }
-    for (; r < r_end; r += rpar) apply(*(const bf16x8*)(x + base + (size_t)r * C), r);
+    for (; r < r_end; r += rpar) apply(*(const bf16x8*)(xs + (size_t)r * ldx), r);
 }
 
 __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -259,7 +276,8 @@ static bool gn_small_fwd(int HW, int C, int G) {
 
 __global__ __launch_bounds__(256) void gn_small_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                           float* __restrict__ stats, int HW, int C, int G, int silu, float eps) {
+                                                           float* __restrict__ stats, int HW, int C, int G, int silu, float eps,
+                                                           const bf16_t* __restrict__ x2 = nullptr, int C1 = 0) {
     __shared__ float red[2][16];
     const int g = blockIdx.x, b = blockIdx.y, cg = C / G, ncc = cg >> 3, n = HW * ncc;
     const size_t base = (size_t)b * HW * C + (size_t)g * cg;
@@ -270,7 +288,11 @@ __global__ __launch_bounds__(256) void gn_small_fwd_kernel(const bf16_t* __restr
         const int idx = threadIdx.x + 256 * k;
         if (idx < n) {
             const int row = idx / ncc, cc = idx - row * ncc;
-            const bf16x8 t = *(const bf16x8*)(x + base + (size_t)row * C + cc * 8);
+            const int c = g * cg + cc * 8;
+            const bf16_t* src = x + base + (size_t)row * C + cc * 8;
+            if (x2 != nullptr)                   // two-source input: see gn_partial_kernel
+                src = c < C1 ? x + ((size_t)b * HW + row) * C1 + c : x2 + ((size_t)b * HW + row) * (C - C1) + (c - C1);
+            const bf16x8 t = *(const bf16x8*)src;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[k][e] = (float)t[e]; s += v[k][e]; }
         }
@@ -550,10 +572,8 @@ long long mi355_groupnorm_scratch_floats(int B, int HW, int C, int G) {
     return (long long)B * strips * C * 2 + (long long)B * strips * G * 2;
 }
 
-// scratch: mi355_groupnorm_scratch_floats().  stats out: [B][G][2] = mean, rstd.
-int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* scratch,
-                        int B, int HW, int C, int G, float eps, int silu, void* stream) {
-    if (!x || !gamma || !beta || !y || !stats || !scratch) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd: null pointer");
+static int gn_fwd_launch(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* stats,
+                         float* scratch, int B, int HW, int C, int G, float eps, int silu, void* stream) {
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -561,15 +581,32 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
     ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 3);
     if (gn_small_fwd(HW, C, G)) {
         hipLaunchKernelGGL(gn_small_fwd_kernel, dim3(G, B), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, stats,
-                           HW, C, G, silu, eps);
+                           HW, C, G, silu, eps, (const bf16_t*)x2, C1);
         return mi355_check_launch("groupnorm_fwd(small)");
     }
     const size_t sh = (size_t)threads * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x, nullptr,
-                       nullptr, nullptr, nullptr, gpart, nullptr, HW, C, G, rows, 0);
+                       nullptr, nullptr, nullptr, gpart, nullptr, HW, C, G, rows, 0, (const bf16_t*)x2, C1);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st, (const bf16_t*)x,
-                       gpart, stats, gamma, beta, (bf16_t*)y, HW, C, G, rows, silu, eps);
+                       gpart, stats, gamma, beta, (bf16_t*)y, HW, C, G, rows, silu, eps, (const bf16_t*)x2, C1);
     return mi355_check_launch("groupnorm_fwd");
+}
+
+// scratch: mi355_groupnorm_scratch_floats().  stats out: [B][G][2] = mean, rstd.
+int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* scratch,
+                        int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || !scratch) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd: null pointer");
+    return gn_fwd_launch(x, nullptr, 0, gamma, beta, y, stats, scratch, B, HW, C, G, eps, silu, stream);
+}
+
+// The same on the channel concatenation [x1 | x2] (x1: [B][HW][C1], x2: [B][HW][C2]) without materialising it: the input
+// of the up-path residual blocks (hidden state | skip connection).  y: [B][HW][C1 + C2].  scratch:
+// mi355_groupnorm_scratch_floats(B, HW, C1 + C2, G).
+int mi355_groupnorm_fwd_cat(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta, void* y,
+                            float* stats, float* scratch, int B, int HW, int G, float eps, int silu, void* stream) {
+    if (!x1 || !x2 || !gamma || !beta || !y || !stats || !scratch) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd_cat: null pointer");
+    if (C1 < 8 || C2 < 8 || (C1 & 7) || (C2 & 7)) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd_cat: C1 = %d, C2 = %d must be multiples of 8", C1, C2);
+    return gn_fwd_launch(x1, x2, C1, gamma, beta, y, stats, scratch, B, HW, C1 + C2, G, eps, silu, stream);
 }
 
 // GroupNorm forward for callers that cannot allocate (HIP graph capture, serving loops that forbid hipMalloc): the

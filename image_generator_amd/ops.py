@@ -59,7 +59,7 @@ def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=F
     assert a.dtype == BF16 and w.dtype == BF16 and a.is_cuda
     M, K = a.shape
     N = w.shape[0]
-    assert w.shape[1] == K and a.stride(1) == 1 and w.is_contiguous()
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1      # w may be a column slice of a wider matrix
     if out is None:
         out = torch.empty((M, N), dtype=F32 if out_fp32 else BF16, device=a.device)
     ws = workspace(a.device)
@@ -72,7 +72,7 @@ def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=F
         assert t16 or lora_t.dtype == F32
         need = r * (N // lora_seg) if lora_seg else r
         assert lora_t.shape[0] == M and lora_b.numel() == N * r and (ldt in (8, 16) and ldt >= need if t16 else ldt == need)
-    check(lib.mi355_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), K, M, N, K, out.data_ptr(), out.stride(0),
+    check(lib.mi355_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K, out.data_ptr(), out.stride(0),
                               1 if out.dtype == F32 else 0, _ptr(bias), _ptr(rowbias), rowbias_div,
                               0 if rowbias is None else rowbias.stride(0), _ptr(residual),
                               0 if residual is None else residual.stride(0), alpha, _ptr(lora_t), ldt, _ptr(lora_b), r,
@@ -636,6 +636,21 @@ class ConvFn(torch.autograd.Function):
         if ctx.flags[2] and ctx.needs_input_grad[4]:
             dres = dy
         return dx, dw, db, drb, dres, None, None, None, None
+
+
+def groupnorm_cat(x1, x2, gamma, beta, groups, eps, silu):
+    """GroupNorm(+SiLU) of torch.cat([x1, x2], -1) for NHWC bf16 tensors, without building the concatenation (inference:
+    no autograd node)."""
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[-1]
+    assert x2.shape[:3] == x1.shape[:3] and x1.dtype == BF16 and x2.dtype == BF16 and x1.is_contiguous() and x2.is_contiguous()
+    y = torch.empty((B, H, W, C1 + C2), dtype=BF16, device=x1.device)
+    stats = torch.empty((B, groups, 2), dtype=F32, device=x1.device)
+    scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C1 + C2, groups)), dtype=F32, device=x1.device)
+    check(lib.mi355_groupnorm_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                      stats.data_ptr(), scratch.data_ptr(), B, H * W, groups, eps, int(silu), _stream()),
+          "groupnorm_fwd_cat")
+    return y
 
 
 class GroupNormFn(torch.autograd.Function):

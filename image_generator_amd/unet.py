@@ -171,6 +171,27 @@ class ResnetBlock(nn.Module):
         res = x if self.conv_shortcut is None else self.conv_shortcut(x)
         return self.conv2(h, residual=res)
 
+    def forward_cat(self, x1, x2, temb_act):
+        """Inference only: the block on torch.cat([x1, x2], -1) (hidden state | skip connection) without building the
+        concatenation - the first normalisation reads both tensors, the 1x1 shortcut is two products that add up."""
+        sc = self.conv_shortcut
+        h = ops.groupnorm_cat(x1, x2, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, True)
+        rb = self._tproj if self._tproj is not None else self.time_emb_proj(temb_act, out_fp32=True)
+        h = self.conv1(h, rowbias=rb)
+        h = self.norm2(h, silu=True)
+        B, H, W, C1 = x1.shape
+        C2 = x2.shape[-1]
+        w = sc.pack.w16.view(sc.pack.cout, C1 + C2)
+        res = ops.gemm(x1.view(-1, C1), w[:, :C1], bias=sc.bias)
+        res = ops.gemm(x2.view(-1, C2), w[:, C1:], residual=res, out=res)
+        return self.conv2(h, residual=res.view(B, H, W, -1))
+
+    def cat_ready(self, x1, x2):
+        sc = self.conv_shortcut
+        return (not torch.is_grad_enabled() and sc is not None and sc.kernel_size == 1 and not sc.padded
+                and x1.shape[-1] % 8 == 0 and x2.shape[-1] % 8 == 0 and x1.is_contiguous() and x2.is_contiguous()
+                and os.environ.get("MI355_NO_CAT_FUSION") != "1")
+
 
 class context_kv_cache:
     """`with context_kv_cache():` - inside, under no_grad, every cross-attention layer projects its text states to keys
@@ -382,8 +403,11 @@ class UpBlock(nn.Module):
 
     def forward(self, x, skips, temb, ctx):
         for j, r in enumerate(self.resnets):
-            x = torch.cat([x, skips.pop()], dim=-1)
-            x = r(x, temb)
+            skip = skips.pop()
+            if r.cat_ready(x, skip):
+                x = r.forward_cat(x, skip, temb)
+            else:
+                x = r(torch.cat([x, skip], dim=-1), temb)
             if self.attentions is not None:
                 x = self.attentions[j](x, ctx)
         if self.upsamplers is not None:

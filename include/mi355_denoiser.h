@@ -170,6 +170,12 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
                         const void* dres, void* stream);
+/* GroupNorm(+SiLU) forward on the channel concatenation [x1 | x2] of two NHWC tensors (x1 [B][HW][C1], x2 [B][HW][C2])
+ * without materialising it: the input of the up-path residual blocks, hidden state | skip connection (the
+ * `torch.cat([hidden_states, res_hidden_states], dim=1)` of the third-party up block the reference calls at
+ * image_generator.py:93-95).  y [B][HW][C1 + C2]; stats and scratch as for mi355_groupnorm_fwd with C = C1 + C2. */
+int mi355_groupnorm_fwd_cat(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta, void* y,
+                            float* stats, float* scratch, int B, int HW, int G, float eps, int silu, void* stream);
 /* mi355_groupnorm_fwd without a scratch argument, for callers that cannot allocate device memory (code under HIP graph
  * capture, serving loops and harnesses that forbid hipMalloc).  No counterpart in the reference.  The strips' partial
  * sums live in a 1 MiB device array built into the library (one copy per GPU, held until the process ends), so the
