@@ -65,14 +65,25 @@ __device__ __forceinline__ void tile_load(bf16x8 (&reg)[NCH], const bf16_t* __re
                                                                         : ((ONES && c * 8 == D) ? one8 : zero8);
     }
 }
-template <int NCH>
+// SWZ: 16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3).  Tiles whose row stride is tr_ld() (64 or 192 B
+// modulo the 256-B bank row, what the transposing reads need) put a column of 16 consecutive rows on only four 16-B bank
+// slots, a 4-way conflict for the row-wise ds_read_b128 of a 16-lane group; with the swizzle the 16 rows cover all 16
+// slots, and a transposing read still sees each row's 64-B block permuted within itself (its four rows share one XOR).
+template <int NCH, bool SWZ = false>
 __device__ __forceinline__ void tile_store(const bf16x8 (&reg)[NCH], char* dst, int dst_ld, int nrows, int ncols8) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int idx = threadIdx.x + 256 * i;
         const int r = idx / ncols8, c = idx - r * ncols8;
-        if (idx < nrows * ncols8) *(bf16x8*)(dst + r * dst_ld + c * 16) = reg[i];
+        if (idx < nrows * ncols8) *(bf16x8*)(dst + r * dst_ld + (SWZ ? c ^ ((r >> 2) & 3) : c) * 16) = reg[i];
     }
+}
+// Byte offsets inside a row of a swizzled tile for the two transposing reads of a fragment (rows tr_row and tr_row + 8 of
+// a 16-row block: XOR hh and hh + 2), without the 64-byte column block.
+__device__ __forceinline__ void tr_cols_swz(int lane, int& c0, int& c1) {
+    const int hh = lane >> 5, chunk = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1), b = (lane & 1) * 8;
+    c0 = (chunk ^ hh) * 16 + b;
+    c1 = (chunk ^ (hh + 2)) * 16 + b;
 }
 
 // =============================================================================================
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 template <int ND, int NO, bool DROP = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p) {
     constexpr int TLD = tr_ld(NO);      // Q / dO tiles [QT][NO*32], row + transposed reads
-    constexpr int QT = 64;              // queries per staged tile (two 32-query MFMA sub-tiles per barrier pair)
+    constexpr int QT = NO <= 2 ? 128 : 64;   // queries per staged tile (32-query MFMA sub-tiles between one barrier pair)
     __shared__ __attribute__((aligned(16))) char smem[2 * QT * TLD + 2 * QT * 4];
     char* Qs = smem;
     char* Gs = smem + QT * TLD;
@@ -337,7 +348,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
         for (int r = 0; r < 16; ++r) { dkT[i][r] = 0.f; dvT[i][r] = 0.f; }
 
     const int tr_row = 4 * hh + ((lane & 15) >> 2);
-    const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+    int tr_c0, tr_c1;
+    tr_cols_swz(lane, tr_c0, tr_c1);
     const int nqt = (p.Nq + QT - 1) / QT;
     constexpr int NCQ = (QT * NO * 4 + 255) / 256;
     bf16x8 qreg[NCQ], greg[NCQ];
@@ -356,8 +368,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
     for (int qt = 0; qt < nqt; ++qt) {
         const int q0 = qt * QT;
         __syncthreads();
-        tile_store(qreg, Qs, TLD, QT, NO * 4);
-        tile_store(greg, Gs, TLD, QT, NO * 4);
+        tile_store<NCQ, true>(qreg, Qs, TLD, QT, NO * 4);
+        tile_store<NCQ, true>(greg, Gs, TLD, QT, NO * 4);
         if (threadIdx.x < 2 * QT) Ls[threadIdx.x] = lreg;
         __syncthreads();
         if (qt + 1 < nqt) {
@@ -367,6 +379,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
         }
 #pragma unroll
         for (int qs = 0; qs < QT / 32; ++qs) {
+        if (q0 + qs * 32 >= p.Nq) break;         // (uniform) the rest of the staged tile is padding
         const char* Qt = Qs + qs * 32 * TLD;
         const char* Gt = Gs + qs * 32 * TLD;
         const float* Lt = Ls + qs * 32;
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < ND; ++ks) {
-            const int off = l31 * TLD + (ks * 16 + 8 * hh) * 2;
+            const int off = l31 * TLD + ((ks * 2 + hh) ^ ((l31 >> 2) & 3)) * 16;
             const bf16x8 aq = *(const bf16x8*)(Qt + off);
             const bf16x8 ag = *(const bf16x8*)(Gt + off);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
@@ -386,8 +399,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float pv = EXP2(fmaf(s[r], p.scale_log2, -Lt[qi]));
-            if (!k_valid) pv = 0.f;
+            // a masked key (lane) is not zeroed here: its column of P / dS only reaches its own rows of dK / dV, which
+            // the store below replaces with zeros (one select per score less in a loop that is bound by vector issue)
+            const float pv = EXP2(fmaf(s[r], p.scale_log2, -Lt[qi]));
             float pd = pv, dpv = dp[r];
             if (DROP) {
                 const bool keep = attn_keep(p, b * p.H + h, q0 + qs * 32 + qi, key);
@@ -402,10 +416,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
         for (int db = 0; db < NO; ++db)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const int off = (16 * st + tr_row) * TLD + db * 64 + tr_col;
-                const bf16x8 ag = cat4(LDS_TR(Gt + off), LDS_TR(Gt + off + 8 * TLD));
+                const int off = (16 * st + tr_row) * TLD + db * 64;
+                const bf16x8 ag = cat4(LDS_TR(Gt + off + tr_c0), LDS_TR(Gt + off + 8 * TLD + tr_c1));
                 dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, pf[st], dvT[db], 0, 0, 0);
-                const bf16x8 aq = cat4(LDS_TR(Qt + off), LDS_TR(Qt + off + 8 * TLD));
+                const bf16x8 aq = cat4(LDS_TR(Qt + off + tr_c0), LDS_TR(Qt + off + 8 * TLD + tr_c1));
                 dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, dsf[st], dkT[db], 0, 0, 0);
             }
         }
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
                                 (bf16_t)(dkT[db][4 * g + 2] * p.scale), (bf16_t)(dkT[db][4 * g + 3] * p.scale)};
                     bf16x4 c = {(bf16_t)dvT[db][4 * g], (bf16_t)dvT[db][4 * g + 1], (bf16_t)dvT[db][4 * g + 2],
                                 (bf16_t)dvT[db][4 * g + 3]};
+                    if (!k_valid) { a = bf16x4{0, 0, 0, 0}; c = a; }        // masked key: no gradient
                     *(bf16x4*)(dK + d) = a;
                     *(bf16x4*)(dV + d) = c;
                 }
@@ -496,7 +511,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
         for (int r = 0; r < 16; ++r) dqT[i][r] = 0.f;
 
     const int tr_row = 4 * hh + ((lane & 15) >> 2);
-    const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+    int tr_c0, tr_c1;
+    tr_cols_swz(lane, tr_c0, tr_c1);
     const int Nk = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;     // valid keys of this sample
     const int nkt = (Nk + 63) / 64;
     constexpr int NCK = (64 * NO * 4 + 255) / 256, NCV = (64 * (DP / 8) + 255) / 256;
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
-        tile_store(kreg, Ks, KLD, 64, NO * 4);
+        tile_store<NCK, true>(kreg, Ks, KLD, 64, NO * 4);
         tile_store(vreg, Vs, VLD, 64, DP / 8);
         __syncthreads();
         if (kt + 1 < nkt) {
@@ -520,17 +536,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < ND; ++ks) {
-                const bf16x8 ak = *(const bf16x8*)(Ks + (kb * 32 + l31) * KLD + (ks * 16 + 8 * hh) * 2);
+                const bf16x8 ak = *(const bf16x8*)(Ks + (kb * 32 + l31) * KLD + ((ks * 2 + hh) ^ ((l31 >> 2) & 3)) * 16);
                 const bf16x8 av = *(const bf16x8*)(Vs + (kb * 32 + l31) * VLD + (ks * 16 + 8 * hh) * 2);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[ks], dp, 0, 0, 0);
             }
             bf16x8 dsf[2];
+            if (k0 + 64 > Nk) {            // only the last key tile can hold padded keys (wave-uniform branch)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= Nk) s[r] = -INFINITY;     // p = exp2(-inf) = 0
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float pv = EXP2(fmaf(s[r], p.scale_log2, -lse));
-                if (key >= Nk) pv = 0.f;
+                const float pv = EXP2(fmaf(s[r], p.scale_log2, -lse));
                 float dpv = dp[r];
                 if (DROP) dpv = attn_keep(p, b * p.H + h, qrow, key) ? dpv * p.drop_scale : 0.f;
                 dsf[r >> 3][r & 7] = (bf16_t)(pv * (dpv - dlt));
@@ -539,8 +559,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
             for (int db = 0; db < NO; ++db)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
-                    const int off = (kb * 32 + 16 * st + tr_row) * KLD + db * 64 + tr_col;
-                    const bf16x8 a = cat4(LDS_TR(Ks + off), LDS_TR(Ks + off + 8 * KLD));
+                    const int off = (kb * 32 + 16 * st + tr_row) * KLD + db * 64;
+                    const bf16x8 a = cat4(LDS_TR(Ks + off + tr_c0), LDS_TR(Ks + off + 8 * KLD + tr_c1));
                     dqT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsf[st], dqT[db], 0, 0, 0);
                 }
         }

@@ -25,5 +25,8 @@ def run(B, H, N, D, T=None):
     tf, tb = e[0].elapsed_time(e[1]) / it * 1e-3, e[1].elapsed_time(e[2]) / it * 1e-3
     fl = 4.0 * B * H * N * Nk * D
     print(f"B{B} H{H} N{N} Nk{Nk} D{D}: fwd {tf*1e6:8.1f} us {fl/tf/1e12:6.1f} TF | bwd {tb*1e6:8.1f} us {2.5*fl/tb/1e12:6.1f} TF")
-run(32, 8, 1024, 40); run(32, 8, 256, 80); run(32, 8, 64, 160); run(32, 8, 1024, 40, 77); run(32, 8, 256, 80, 77)
-run(32, 8, 4096, 40); run(32, 8, 1024, 80); run(32, 8, 256, 160)
+if len(sys.argv) > 1:      # one shape: attn_bench.py B H N D [T]  (under rocprofv3 --stats the per-kernel averages are then this shape's)
+    run(*[int(v) for v in sys.argv[1:]])
+else:
+    run(32, 8, 1024, 40); run(32, 8, 256, 80); run(32, 8, 64, 160); run(32, 8, 1024, 40, 77); run(32, 8, 256, 80, 77)
+    run(32, 8, 4096, 40); run(32, 8, 1024, 80); run(32, 8, 256, 160)
