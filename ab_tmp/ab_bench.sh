@@ -1,0 +1,9 @@
+#!/bin/bash
+# interleaved whole-step A/B on one box: base lib vs working tree
+R=$GRAFT_REPO_ROOT
+for i in 1 2; do
+  for tag in ${TAGS:-base new}; do
+    if [ $tag = new ]; then unset MI355_DENOISER_LIB; else export MI355_DENOISER_LIB=$R/ab_tmp/lib$tag.so; fi
+    timeout -k 10 200 python bench.py --no-cpu-baseline --no-extra --prof-steps 0 ${BENCH_ARGS} 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'], 3), 'ms', round(d['value'], 1))" || exit 1
+  done
+done

@@ -1,0 +1,18 @@
+#!/bin/bash
+# A/B of attention kernels: baseline lib vs working tree, per-kernel averages from rocprofv3 for one shape at a time
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/attn_ab
+mkdir -p $O
+for tag in ${TAGS:-base new}; do
+  if [ $tag = new ]; then unset MI355_DENOISER_LIB; else export MI355_DENOISER_LIB=$R/ab_tmp/lib$tag.so; fi
+  IFS=';' read -ra SH <<< "${SHAPES:-32 8 1024 40;32 8 1024 40 77;32 8 256 80;32 8 4096 40}"
+  for shape in "${SH[@]}"; do
+    n=$(echo $shape | tr ' ' '_')
+    timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $O/${tag}_$n -o p -- python3 $R/tools/attn_bench.py $shape > $O/${tag}_$n.log 2>&1
+    f=$(find $O/${tag}_$n -name '*kernel_stats.csv' | head -1)
+    echo "== $tag $shape"; tail -1 $O/${tag}_$n.log
+    grep -E "attn_" $f | awk -F, '{printf "   %-60s calls %s avg_ns %s\n", substr($1,1,60), $2, $4}'
+  done
+done

@@ -57,12 +57,23 @@ struct GemmArgs {
     bf16_t* preact;          // geglu only, optional: [M][2F] pre-activation (hidden | gate) kept for the backward pass
     int tiles_m, tiles_n;
     ConvGeom g;
+    // AMODE_DENSE_CAT: A is the column concatenation [A | A2] read in place - A holds the first K1 columns (row stride
+    // lda), A2 the other K - K1 (row stride lda2); K1 is a multiple of the 64-deep k-tile
+    const bf16_t* A2;
+    int K1, lda2;
+    unsigned a2_bytes;
+    // two-destination output (any kernel): columns n >= N1 go to out2 [M][N - N1] instead; N1 is a multiple of every tile
+    // width, so a tile never straddles the two
+    void* out2;
+    int N1;
 };
 
 // AMODE_DENSE_LORA: dense A with the low-rank term in the epilogue - a kernel variant of its own so that every other
 // GEMM keeps the short epilogue (carrying the low-rank code path cost them 0.3 ms per training step)
-enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2, AMODE_DENSE_LORA = 3 };
-__host__ __device__ constexpr bool amode_dense(int amode) { return amode == AMODE_DENSE || amode == AMODE_DENSE_LORA; }
+enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2, AMODE_DENSE_LORA = 3, AMODE_DENSE_CAT = 4 };
+__host__ __device__ constexpr bool amode_dense(int amode) {
+    return amode == AMODE_DENSE || amode == AMODE_DENSE_LORA || amode == AMODE_DENSE_CAT;
+}
 
 __device__ __forceinline__ float gemm_gelu_erf(float x) { return gelu_erf_f(x); }
 
@@ -161,6 +172,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     }
 
     // ---- epilogue through LDS, 64 rows at a time
+    char* outp = (char*)p.out;               // destination of this tile's columns (two-destination output: see GemmArgs)
+    int ldo = p.ldo, nsh = 0;
+    if (p.out2 != nullptr && n0 >= p.N1) { outp = (char*)p.out2; ldo = p.N - p.N1; nsh = p.N1; }
     float* ep = (float*)smem;
     // Low-rank factors of this tile's BN columns, staged once behind the staging rows: read from global memory per
     // 8-column chunk they cost 128 B of L1 traffic per 16 B of output (measured +87 us on a 38 us GEMM).
@@ -283,14 +297,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
             }
             if (p.out_fp32) {
-                float* o = (float*)p.out + (size_t)m * p.ldo + n;
+                float* o = (float*)outp + (size_t)m * ldo + n - nsh;
                 *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
                 *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
             } else {
                 bf16x8 ov;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-                *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = ov;
+                *(bf16x8*)((bf16_t*)outp + (size_t)m * ldo + n - nsh) = ov;
             }
         }
     }
@@ -505,10 +519,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw, 0, b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(AMODE == AMODE_DENSE_CAT ? p.A2 : p.A), 0, AMODE == AMODE_DENSE_CAT ? p.a2_bytes : 0u, 0x00020000);
 
     const int sr = lane >> 3;               // row inside the 8-row piece
     const int kc = (lane & 7) ^ sr;         // k-chunk fetched by this lane (source-side swizzle)
     int a_voff[A_P];                         // dense: byte offset of (row, kc); conv: pixel index of (b,0,0) or -1
+    int a_voff2[AMODE == AMODE_DENSE_CAT ? A_P : 1];     // the same in the second source
     int a_iy0[A_P], a_ix0[A_P];
     const int pad = p.g.pad;
 #pragma unroll
@@ -517,6 +534,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
         const bool ok = m < p.M;
         if constexpr (amode_dense(AMODE)) {
             a_voff[j] = ok ? (m * p.lda + kc * 8) * 2 : OOB_OFF;
+            if constexpr (AMODE == AMODE_DENSE_CAT) a_voff2[j] = ok ? (m * p.lda2 + kc * 8) * 2 : OOB_OFF;
             a_iy0[j] = a_ix0[j] = 0;
         } else {
             const int mm = ok ? m : 0;
@@ -572,7 +590,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     auto issue = [&](int kt, int stage) {
         char* As = smem + stage * STAGE;
         char* Bs = As + BM * 128;
-        if constexpr (amode_dense(AMODE)) {
+        if constexpr (AMODE == AMODE_DENSE_CAT) {
+            if (kt * BK < p.K1) {            // (uniform) the k-tile lies in the first source ...
+                const int soff = kt * (BK * 2);
+#pragma unroll
+                for (int j = 0; j < A_P; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + NW * j) * 1024), 16, a_voff[j], soff, 0, 0);
+            } else {                         // ... or in the second
+                const int soff = (kt * BK - p.K1) * 2;
+#pragma unroll
+                for (int j = 0; j < A_P; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, LDS_PTR(As + (wave + NW * j) * 1024), 16, a_voff2[j], soff, 0, 0);
+            }
+        } else if constexpr (amode_dense(AMODE)) {
             const int soff = kt * (BK * 2);
 #pragma unroll
             for (int j = 0; j < A_P; ++j)
@@ -1149,15 +1179,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
         }
+        char* outp = (char*)p.out;
+        int ldo = p.ldo, nn = n;
+        if (p.out2 != nullptr && n >= p.N1) { outp = (char*)p.out2; ldo = p.N - p.N1; nn = n - p.N1; }
         if (p.out_fp32) {
-            float* o = (float*)p.out + (size_t)m * p.ldo + n;
+            float* o = (float*)outp + (size_t)m * ldo + nn;
             *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
             *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
         } else {
             bf16x8 ov;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-            *(bf16x8*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = ov;
+            *(bf16x8*)((bf16_t*)outp + (size_t)m * ldo + nn) = ov;
         }
     }
 }
@@ -1306,7 +1339,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
         static const int bm256 = getenv("MI355_GEMM_BM256") ? atoi(getenv("MI355_GEMM_BM256")) : 1;
         const int t256 = ((a.M + 255) / 256) * a.tiles_n;
         static const int wide_min = getenv("MI355_GEMM_WIDE_MIN") ? atoi(getenv("MI355_GEMM_WIDE_MIN")) : 512;
-        if (bm256 && dma_ok && bn == 160 && sk == 1 && t256 >= wide_min) {       // at least two workgroups per CU
+        if (bm256 && dma_ok && bn == 160 && sk == 1 && t256 >= wide_min && amode != AMODE_DENSE_CAT) {       // at least two workgroups per CU
             a.bm = 256;
             a.tiles_m = (a.M + 255) / 256;
         }
@@ -1319,7 +1352,8 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
         const int tn = a.geglu ? (a.N / 2 + 159) / 160 : a.N / 320;
         const int tpp = ((a.M + 255) / 256) * tn;
         const int rounds = (tpp + 255) / 256;
-        if (pp_on && g_tune[1] == 0 && dma_ok && sk == 1 && amode != AMODE_DENSE_LORA && a.K % 32 == 0 && a.K >= 128 &&
+        if (pp_on && g_tune[1] == 0 && dma_ok && sk == 1 && amode != AMODE_DENSE_LORA && amode != AMODE_DENSE_CAT &&
+            a.K % 32 == 0 && a.K >= 128 &&
             (a.K >= 512 || tpp >= 1024 || g_tune[3]) &&      // short loops: one workgroup per CU cannot hide its epilogue
             (a.geglu ? (a.N / 2) % 160 == 0 : a.N % 320 == 0) && tpp * 100 >= rounds * 256 * pp_fill) {
             use_pp = true;
@@ -1336,6 +1370,10 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
         rc = amode == AMODE_DENSE ? launch_gemm_wide<AMODE_DENSE>(a, ab, bb, s)
              : amode == AMODE_DENSE_LORA ? launch_gemm_wide<AMODE_DENSE_LORA>(a, ab, bb, s)
                                          : launch_gemm_wide<AMODE_CONV_FAST>(a, ab, bb, s);
+    } else if (amode == AMODE_DENSE_CAT) {
+        if (!dma_ok || bn != 160)
+            return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_cat: needs N %% 160 == 0, K1, K2 %% 64 == 0 and operands < 2 GB");
+        rc = launch_gemm_dma<160, AMODE_DENSE_CAT>(a, (unsigned)(((double)(a.M - 1) * a.lda + a.K1) * 2.0), (unsigned)b_sz, s);
     } else if (dma_ok) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
 #define DISPATCH_DMA(BN) (amode == AMODE_DENSE ? launch_gemm_dma<BN, AMODE_DENSE>(a, ab, bb, s) \
@@ -1380,6 +1418,37 @@ size_t mi355_gemm_workspace_bytes(int M, int N) {
     size_t b = (size_t)16 * M * N * sizeof(float);
     const size_t cap = (size_t)256 << 20;
     return b > cap ? cap : b;
+}
+
+// out [M][N] = [A1 | A2] Bw^T + bias with the column concatenation read in place (A1 [M][K1], A2 [M][K2], both
+// contiguous; Bw [N][K1 + K2], row stride ldb).  K1 and K2 must be multiples of 64, N of 160.
+int mi355_gemm_cat_bf16(const void* A1, int K1, const void* A2, int K2, const void* Bw, int ldb, int M, int N, void* out,
+                        int ldo, const float* bias, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A1 || !A2 || !Bw || !out) return mi355_fail(MI355_ERR_ARG, "gemm_cat: null pointer");
+    if (K1 < 64 || K2 < 64 || (K1 & 63) || (K2 & 63) || N % 160)
+        return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_cat: K1 = %d, K2 = %d must be multiples of 64 and N = %d of 160", K1, K2, N);
+    const double a2_sz = (double)M * K2 * 2.0;
+    if (a2_sz >= 2.0e9) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_cat: operand of 2 GB or more");
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A1; a.A2 = (const bf16_t*)A2; a.K1 = K1; a.lda = K1; a.lda2 = K2; a.a2_bytes = (unsigned)a2_sz;
+    a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N; a.K = K1 + K2; a.ldb = ldb;
+    a.out = out; a.ldo = ldo; a.bias = bias; a.alpha = 1.f;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
+    return run_gemm(a, AMODE_DENSE_CAT, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// [out1 | out2] = A Bw^T written as two tensors: out1 [M][N1] takes the first N1 columns, out2 [M][N2] the rest
+// (A [M][K] with row stride lda, Bw [N1 + N2][K] with row stride ldb).  N1 must be a multiple of 320, N2 of 8.
+int mi355_gemm_split_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N1, int N2, int K, void* out1,
+                          void* out2, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !Bw || !out1 || !out2) return mi355_fail(MI355_ERR_ARG, "gemm_split: null pointer");
+    if (N1 < 320 || N1 % 320 || N2 < 8 || (N2 & 7))
+        return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_split: N1 = %d must be a multiple of 320, N2 = %d of 8", N1, N2);
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N1 + N2; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.out = out1; a.ldo = N1; a.out2 = out2; a.N1 = N1; a.alpha = 1.f;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
+    return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,

@@ -203,7 +203,8 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
                                     const float* __restrict__ stats, const float* __restrict__ gpart,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     bf16_t* __restrict__ dx, int HW, int C, int G, int rows_per_block, int silu,
-                                    const bf16_t* __restrict__ dres) {
+                                    const bf16_t* __restrict__ dres, const bf16_t* __restrict__ x2 = nullptr, int C1 = 0,
+                                    bf16_t* __restrict__ dx2 = nullptr, const bf16_t* __restrict__ dres2 = nullptr) {
     extern __shared__ float gs[];            // [G][2] = {sum_c gamma*sum dz, sum_c gamma*sum dz*xhat}
     const int nc = C >> 3;
     const int b = blockIdx.y;
@@ -226,6 +227,17 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
         m2[e] = gs[g * 2 + 1] * inv_n;
     }
     const size_t base = (size_t)b * HW * C + c8 * 8;
+    // this thread's chunk of every row of x / dres / dx: p + (b * HW + r) * ldx.  Two-source input (see gn_partial_kernel):
+    // the chunk lies in x (rows of C1) or in x2 (rows of C - C1), and so do its gradient and its bypass gradient.
+    int ldx = C;
+    size_t off = (size_t)c8 * 8;
+    const bf16_t* xs = x;
+    const bf16_t* rsrc = dres;
+    bf16_t* ds = dx;
+    if (x2 != nullptr) {
+        if (c8 * 8 < C1) { ldx = C1; } else { xs = x2; rsrc = dres2; ds = dx2; off = (size_t)(c8 * 8 - C1); ldx = C - C1; }
+    }
+    off += (size_t)b * HW * ldx;
     auto apply = [&](const bf16x8& xv, const bf16x8& dv, int r) {
         bf16x8 ov;
 #pragma unroll
@@ -235,26 +247,26 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
             if (silu) dz *= silu_grad_f(xh * ga[e] + be[e]);
             ov[e] = (bf16_t)(rs[e] * (ga[e] * dz - m1[e] - xh * m2[e]));
         }
-        if (dres) {         // gradient of the branch that bypasses the normalisation (residual / shortcut input)
-            const bf16x8 rv = *(const bf16x8*)(dres + base + (size_t)r * C);
+        if (rsrc) {          // gradient of the branch that bypasses the normalisation (residual / shortcut input)
+            const bf16x8 rv = *(const bf16x8*)(rsrc + off + (size_t)r * ldx);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)((float)ov[e] + (float)rv[e]);
         }
-        *(bf16x8*)(dx + base + (size_t)r * C) = ov;
+        *(bf16x8*)(ds + off + (size_t)r * ldx) = ov;
     };
     int r = r_begin + rp;
     for (; r + 3 * rpar < r_end; r += 4 * rpar) {
         bf16x8 xv[4], dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            xv[u] = *(const bf16x8*)(x + base + (size_t)(r + u * rpar) * C);
+            xv[u] = *(const bf16x8*)(xs + off + (size_t)(r + u * rpar) * ldx);
             dv[u] = *(const bf16x8*)(dy + base + (size_t)(r + u * rpar) * C);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) apply(xv[u], dv[u], r + u * rpar);
     }
     for (; r < r_end; r += rpar)
-        apply(*(const bf16x8*)(x + base + (size_t)r * C), *(const bf16x8*)(dy + base + (size_t)r * C), r);
+        apply(*(const bf16x8*)(xs + off + (size_t)r * ldx), *(const bf16x8*)(dy + base + (size_t)r * C), r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,7 +349,10 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const bf16_t* __restr
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, bf16_t* __restrict__ dx,
                                                            float* __restrict__ cpart, const bf16_t* __restrict__ dres,
-                                                           int HW, int C, int G, int silu) {
+                                                           int HW, int C, int G, int silu,
+                                                           const bf16_t* __restrict__ x2 = nullptr, int C1 = 0,
+                                                           bf16_t* __restrict__ dx2 = nullptr,
+                                                           const bf16_t* __restrict__ dres2 = nullptr) {
     extern __shared__ float pc[];            // [chunk][16]: 8 x dz, 8 x dz*xhat per chunk (parameter gradients only)
     __shared__ float red[2][16];
     const int g = blockIdx.x, b = blockIdx.y, cg = C / G, ncc = cg >> 3, n = HW * ncc;
@@ -350,7 +365,12 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const bf16_t* __restr
         const int idx = threadIdx.x + 256 * k;
         if (idx < n) {
             const int row = idx / ncc, cc = idx - row * ncc;
-            const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)row * C + cc * 8);
+            const bf16_t* xsrc = x + base + (size_t)row * C + cc * 8;
+            if (x2 != nullptr) {                 // two-source input: see gn_partial_kernel
+                const int c = g * cg + cc * 8;
+                xsrc = c < C1 ? x + ((size_t)b * HW + row) * C1 + c : x2 + ((size_t)b * HW + row) * (C - C1) + (c - C1);
+            }
+            const bf16x8 xv = *(const bf16x8*)xsrc;
             const bf16x8 dv = *(const bf16x8*)(dy + base + (size_t)row * C + cc * 8);
             const float* ga = gamma + g * cg + cc * 8;
             const float* be = beta + g * cg + cc * 8;
@@ -382,12 +402,20 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const bf16_t* __restr
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(rstd * (gw[k][e] * dz[k][e] - m1 - xh[k][e] * m2));
-            if (dres) {
-                const bf16x8 rv = *(const bf16x8*)(dres + base + (size_t)row * C + cc * 8);
+            size_t doff = base + (size_t)row * C + cc * 8;
+            const bf16_t* rsrc = dres;
+            bf16_t* ddst = dx;
+            if (x2 != nullptr) {
+                const int c = g * cg + cc * 8;
+                if (c < C1) doff = ((size_t)b * HW + row) * C1 + c;
+                else { doff = ((size_t)b * HW + row) * (C - C1) + (c - C1); rsrc = dres2; ddst = dx2; }
+            }
+            if (rsrc) {
+                const bf16x8 rv = *(const bf16x8*)(rsrc + doff);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)o[e] + (float)rv[e]);
             }
-            *(bf16x8*)(dx + base + (size_t)row * C + cc * 8) = o;
+            *(bf16x8*)(ddst + doff) = o;
         }
     }
     if (cpart) {
@@ -655,12 +683,9 @@ int mi355_groupnorm_fwd_static(const void* x, const float* gamma, const float* b
     return mi355_groupnorm_fwd(x, gamma, beta, y, stats, scratch, B, HW, C, G, eps, silu, stream);
 }
 
-// scratch: mi355_groupnorm_scratch_floats().
-int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
-                        void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
-                        const void* dres, void* stream) {
-    if (!x || !dy || !stats || !gamma || !beta || !dx || !scratch || (!dgamma != !dbeta))
-        return mi355_fail(MI355_ERR_ARG, "groupnorm_bwd: null pointer");
+static int gn_bwd_launch(const void* x, const void* x2, int C1, const void* dy, const float* stats, const float* gamma,
+                         const float* beta, void* dx, void* dx2, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C,
+                         int G, int silu, const void* dres, const void* dres2, void* stream) {
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -670,21 +695,43 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
     if (gn_small(HW, C, G)) {
         const size_t shs = (size_t)HW * (C / G / 8) * 16 * sizeof(float);
         hipLaunchKernelGGL(gn_small_bwd_kernel, dim3(G, B), dim3(256), shs, st, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma,
-                           beta, (bf16_t*)dx, cpart, (const bf16_t*)dres, HW, C, G, silu);
+                           beta, (bf16_t*)dx, cpart, (const bf16_t*)dres, HW, C, G, silu, (const bf16_t*)x2, C1, (bf16_t*)dx2,
+                           (const bf16_t*)dres2);
         if (dgamma)
             hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B, 2 * C, dgamma, C);
         return mi355_check_launch("groupnorm_bwd(small)");
     }
     const size_t sh = (size_t)threads * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x,
-                       (const bf16_t*)dy, stats, gamma, beta, gpart, cpart, HW, C, G, rows, silu);
+                       (const bf16_t*)dy, stats, gamma, beta, gpart, cpart, HW, C, G, rows, silu, (const bf16_t*)x2, C1);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st,
                        (const bf16_t*)x, (const bf16_t*)dy, stats, gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu,
-                       (const bf16_t*)dres);
+                       (const bf16_t*)dres, (const bf16_t*)x2, C1, (bf16_t*)dx2, (const bf16_t*)dres2);
     // dbeta = column sums of the first plane, dgamma of the second (skipped for frozen affine parameters)
     if (dgamma)
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B * strips, 2 * C, dgamma, C);
     return mi355_check_launch("groupnorm_bwd");
+}
+
+// scratch: mi355_groupnorm_scratch_floats().
+int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                        void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
+                        const void* dres, void* stream) {
+    if (!x || !dy || !stats || !gamma || !beta || !dx || !scratch || (!dgamma != !dbeta))
+        return mi355_fail(MI355_ERR_ARG, "groupnorm_bwd: null pointer");
+    return gn_bwd_launch(x, nullptr, 0, dy, stats, gamma, beta, dx, nullptr, dgamma, dbeta, scratch, B, HW, C, G, silu, dres,
+                         nullptr, stream);
+}
+
+// Backward of mi355_groupnorm_fwd_cat: the input gradient leaves as two tensors shaped like x1 and x2.
+int mi355_groupnorm_bwd_cat(const void* x1, int C1, const void* x2, int C2, const void* dy, const float* stats,
+                            const float* gamma, const float* beta, void* dx1, void* dx2, float* dgamma, float* dbeta,
+                            float* scratch, int B, int HW, int G, int silu, const void* dres1, const void* dres2, void* stream) {
+    if (!x1 || !x2 || !dy || !stats || !gamma || !beta || !dx1 || !dx2 || !scratch || (!dgamma != !dbeta) || (!dres1 != !dres2))
+        return mi355_fail(MI355_ERR_ARG, "groupnorm_bwd_cat: null pointer");
+    if (C1 < 8 || C2 < 8 || (C1 & 7) || (C2 & 7)) return mi355_fail(MI355_ERR_ARG, "groupnorm_bwd_cat: C1 = %d, C2 = %d must be multiples of 8", C1, C2);
+    return gn_bwd_launch(x1, x2, C1, dy, stats, gamma, beta, dx1, dx2, dgamma, dbeta, scratch, B, HW, C1 + C2, G, silu, dres1,
+                         dres2, stream);
 }
 
 int mi355_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C,

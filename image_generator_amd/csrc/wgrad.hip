@@ -31,6 +31,9 @@ struct WgradArgs {
                         // gradient norm then needs no second pass over these gradients)
     int gci;            // block order: ci tiles are walked in groups of gci (see wgrad_dma_blocks)
     bf16_t* dw16;       // optional: unsplit jobs store bf16 here (same [Cout][taps][Cin] layout) INSTEAD of fp32 into dw
+    const bf16_t* x2;   // dense jobs only, optional: x is the channel concatenation [x | x2] read in place - x holds the
+    int C1;             //   first C1 input channels (rows of C1), x2 the other Cin - C1 (rows of Cin - C1); C1 is a multiple
+    unsigned x2_bytes;  //   of the 160-channel tile, so every ci tile lies in one of the two tensors
 };
 
 constexpr int WG_SQ_SLOTS = 1024;   // partial sums of squares are spread over this many addresses (atomics to one address serialise)
@@ -276,8 +279,16 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int blo
     int kt_end = kt_begin + p.kt_per_split;
     if (kt_end > nkt_total) kt_end = nkt_total;
 
+    // x operand of this ci tile: the tensor itself, or the half of a two-source concatenation the tile lies in
+    const bf16_t* xb = p.x;
+    unsigned xb_bytes = p.x_bytes;
+    int ldx = p.ldx, cib = ci0, cin_lim = p.Cin;
+    if (MODE == 0 && p.x2 != nullptr) {
+        if (ci0 >= p.C1) { xb = p.x2; xb_bytes = p.x2_bytes; ldx = p.Cin - p.C1; cib = ci0 - p.C1; cin_lim = ldx; }
+        else { ldx = p.C1; cin_lim = p.C1; }
+    }
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, xb_bytes, 0x00020000);
 
     // Wave w moves pieces w, w+4, w+8 (< 11) of BOTH operand tiles; a piece is 64 consecutive 16-byte slots
     // of the [32][22-chunk] tile image, so a lane owns the same (pixel row, channel chunk) of its pieces for
@@ -286,7 +297,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int blo
     // and a zero step.
     int pm[3], offA[3], offB[3], chB[3];
     const int stepA = WD_BK * p.Cout * 2;
-    const int stepB = MODE == 0 ? WD_BK * p.ldx * 2 : WD_BK * p.Cin * 2;
+    const int stepB = MODE == 0 ? WD_BK * ldx * 2 : WD_BK * p.Cin * 2;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int q = (wave + 4 * j) * 64 + lane;
@@ -298,8 +309,8 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, const int blo
         // an out-of-range offset stays out of range under the per-tile steps (operands are < 2 GB)
         const bool okA = pch < 20 && co0 + ch < p.Cout;
         offA[j] = okA ? (pm[j] * p.Cout + co0 + ch) * 2 : OOB_OFF;
-        const bool okB = pch < 20 && ci0 + ch < p.Cin;
-        if (MODE == 0) offB[j] = okB ? (pm[j] * p.ldx + ci0 + ch) * 2 : OOB_OFF;
+        const bool okB = pch < 20 && (MODE == 0 ? cib + ch < cin_lim : ci0 + ch < p.Cin);
+        if (MODE == 0) offB[j] = okB ? (pm[j] * ldx + cib + ch) * 2 : OOB_OFF;
         else if (MODE == 1) offB[j] = okB ? ((pm[j] + dyy * p.W + dxx) * p.Cin + ci0 + ch) * 2 : OOB_OFF;   // used only when the tap is in range
         else offB[j] = okB ? 0 : OOB_OFF;
     }
@@ -677,6 +688,23 @@ int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* d
     j->nblocks = (blocks + 7) & ~7;
     if (splits_out) *splits_out = a.splits;
     return j->nblocks;
+}
+
+// The dense job whose x operand is the channel concatenation [x1 | x2] (x1: [M][C1], x2: [M][C2]) read in place:
+// dw is [Cout][C1 + C2] as if the concatenation had been built.  C1 must be a multiple of 160 (the channel tile).
+int mi355_wgrad_job_fill_cat(void* host_job, const void* dy, const void* x1, int C1, const void* x2, int C2, float* dw,
+                             float* dbias, int M, int Cout, int first_block, int* splits_out, float* sumsq_slots, void* dw_bf16) {
+    if (!x1 || !x2) return mi355_fail(MI355_ERR_ARG, "wgrad_job_fill_cat: null pointer");
+    if (C1 < WG_BT || C1 % WG_BT || C2 < 8 || (C2 & 7))
+        return mi355_fail(MI355_ERR_UNSUPPORTED, "wgrad_job_fill_cat: C1 = %d must be a multiple of %d, C2 = %d of 8", C1, WG_BT, C2);
+    const int nb = mi355_wgrad_job_fill(host_job, dy, x1, dw, dbias, M, 1, 1, C1 + C2, Cout, 1, 1, 0, 1, 1, first_block, splits_out,
+                                        sumsq_slots, dw_bf16);
+    if (nb < 0) return nb;
+    WgradArgs& a = ((WgradJob*)host_job)->a;
+    const double x1_sz = (double)M * C1 * 2.0, x2_sz = (double)M * C2 * 2.0;
+    a.x2 = (const bf16_t*)x2; a.C1 = C1;
+    a.x_bytes = (unsigned)x1_sz; a.x2_bytes = (unsigned)x2_sz;        // (both below the 2 GB the concatenation was checked against)
+    return nb;
 }
 
 // jobs: DEVICE copy of njobs records; total_blocks = sum of their block counts.

@@ -80,6 +80,33 @@ def gemm(a, w, bias=None, rowbias=None, rowbias_div=1, residual=None, out_fp32=F
     return out
 
 
+def gemm_cat(a1, a2, w, bias=None):
+    """bf16 [M, N] = [a1 | a2] @ w[N, K1 + K2]^T (+ bias) with the concatenation read in place."""
+    M, K1 = a1.shape
+    K2 = a2.shape[1]
+    N = w.shape[0]
+    assert a1.dtype == BF16 and a2.dtype == BF16 and w.dtype == BF16 and a1.is_contiguous() and a2.is_contiguous()
+    assert a2.shape[0] == M and w.shape[1] == K1 + K2 and w.stride(1) == 1
+    out = torch.empty((M, N), dtype=BF16, device=a1.device)
+    ws = workspace(a1.device)
+    check(lib.mi355_gemm_cat_bf16(a1.data_ptr(), K1, a2.data_ptr(), K2, w.data_ptr(), w.stride(0), M, N, out.data_ptr(), N,
+                                  _ptr(bias), ws.data_ptr(), ws.numel(), _stream()), "gemm_cat")
+    return out
+
+
+def gemm_split(a, w, n1):
+    """(bf16 [M, n1], bf16 [M, N - n1]) = column blocks of a @ w[N, K]^T, written as two tensors."""
+    M, K = a.shape
+    N = w.shape[0]
+    assert a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
+    o1 = torch.empty((M, n1), dtype=BF16, device=a.device)
+    o2 = torch.empty((M, N - n1), dtype=BF16, device=a.device)
+    ws = workspace(a.device)
+    check(lib.mi355_gemm_split_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, n1, N - n1, K, o1.data_ptr(),
+                                    o2.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "gemm_split")
+    return o1, o2
+
+
 def gemm_skinny(a, w, alpha=1.0):
     """bf16 [M, W] = alpha * a[M, K] @ w[W, K]^T for W in (8, 16): one launch, no split-K workspace."""
     M, K = a.shape
@@ -249,6 +276,32 @@ class WgradQueue:
         self._blocks += nb
         self._flops += 2.0 * B * Ho * Wo * cout * ksize * ksize * cin
         self._refs.append((dy, x))
+        if callback is not None:
+            self._cbs.append(callback)
+        if self._blocks >= self.flush_blocks or self._n == self.max_jobs:
+            self.flush()
+
+    def push_cat(self, dy, x1, x2, dw, dbias, callback=None):
+        """The dense job whose input is the channel concatenation [x1 | x2] (2-d views, rows = pixels), read in place."""
+        M, cout = dy.shape
+        c1, c2 = x1.shape[1], x2.shape[1]
+        dwp = dw.data_ptr()
+        tracked = self._tr_lo <= dwp < self._tr_hi
+        slots = self._tr_slots if tracked else None
+        dw16 = self._tr_stage + (dwp - self._tr_lo) // 2 if (tracked and self._tr_stage is not None) else None
+        nb = lib.mi355_wgrad_job_fill_cat(self._host.data_ptr() + self._n * self.jb, dy.data_ptr(), x1.data_ptr(), c1,
+                                          x2.data_ptr(), c2, dwp, _ptr(dbias), M, cout, self._blocks,
+                                          ctypes.byref(self._splits), slots, dw16)
+        check(min(nb, 0), "wgrad_job_fill_cat")
+        if tracked and self._splits.value == 1:
+            self.covered.append((dwp, cout * (c1 + c2)))
+            self.covered_map[dwp] = cout * (c1 + c2)
+        if self.zero_split_outputs and self._splits.value > 1:
+            self._zero.append((dw.data_ptr(), dw.numel() * 4))
+        self._n += 1
+        self._blocks += nb
+        self._flops += 2.0 * M * cout * (c1 + c2)
+        self._refs.append((dy, x1, x2))
         if callback is not None:
             self._cbs.append(callback)
         if self._blocks >= self.flush_blocks or self._n == self.max_jobs:
@@ -651,6 +704,90 @@ def groupnorm_cat(x1, x2, gamma, beta, groups, eps, silu):
                                       stats.data_ptr(), scratch.data_ptr(), B, H * W, groups, eps, int(silu), _stream()),
           "groupnorm_fwd_cat")
     return y
+
+
+class CatNormShortcutFn(torch.autograd.Function):
+    """Head of an up-path residual block on the channel concatenation [x1 | x2] (hidden state | skip connection) without
+    building it, for training: returns (GroupNorm+SiLU of the concatenation, its 1x1 shortcut convolution).  Backward
+    writes the two input gradients as separate tensors, the shortcut's data gradient added inside the normalisation
+    kernel; the shortcut's weight gradient is one deferred job that reads both tensors in place.  A trained shortcut
+    weight needs its preassigned gradient buffer (`cat_train_ready`)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, groups, eps, silu, gdst, pack, sc_bias, sc_weight):
+        B, H, W, C1 = x1.shape
+        C2 = x2.shape[-1]
+        C = C1 + C2
+        y = torch.empty((B, H, W, C), dtype=BF16, device=x1.device)
+        stats = torch.empty((B, groups, 2), dtype=F32, device=x1.device)
+        scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, groups)), dtype=F32, device=x1.device)
+        check(lib.mi355_groupnorm_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                          stats.data_ptr(), scratch.data_ptr(), B, H * W, groups, eps, int(silu), _stream()),
+              "groupnorm_fwd_cat")
+        w = pack.w16.view(pack.n, C)
+        if C1 % 64 == 0 and C2 % 64 == 0 and pack.n % 160 == 0:
+            res = gemm_cat(x1.view(-1, C1), x2.view(-1, C2), w, bias=sc_bias)
+        else:
+            res = gemm(x1.view(-1, C1), w[:, :C1], bias=sc_bias)
+            res = gemm(x2.view(-1, C2), w[:, C1:], residual=res, out=res)
+        ctx.save_for_backward(x1, x2, stats, gamma, beta)
+        ctx.groups, ctx.silu, ctx.gdst, ctx.pack = groups, silu, gdst, pack
+        ctx.has_bias = sc_bias is not None
+        return y, res.view(B, H, W, pack.n)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x1, x2, stats, gamma, beta = ctx.saved_tensors
+        pack, G = ctx.pack, ctx.groups
+        B, H, W, C1 = x1.shape
+        C2 = x2.shape[-1]
+        C = C1 + C2
+        dy = dy.contiguous()
+        dr2 = (dres if dres.dtype == BF16 else dres.to(BF16)).contiguous().view(-1, pack.n)
+        needs = ctx.needs_input_grad
+        # shortcut data gradients, one per source; the normalisation kernel adds them to its own
+        wt = pack.w16_t.view(C, pack.n)
+        if C1 % 320 == 0:
+            d1, d2 = gemm_split(dr2, wt, C1)
+        else:
+            d1, d2 = gemm(dr2, wt[:C1]), gemm(dr2, wt[C1:])
+        dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+        direct = ctx.gdst is not None
+        frozen = not (needs[2] or needs[3])
+        dg, db = ctx.gdst if direct else ((None, None) if frozen else (torch.empty_like(gamma), torch.empty_like(beta)))
+        nsc = int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, G))
+        scratch = torch.empty(nsc, dtype=F32, device=x1.device)
+        deferred = direct and not frozen and _REDUCE_QUEUE is not None
+        check(lib.mi355_groupnorm_bwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
+                                          beta.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), None if (deferred or frozen) else _ptr(dg),
+                                          None if (deferred or frozen) else _ptr(db), scratch.data_ptr(), B, H * W, G, int(ctx.silu),
+                                          d1.data_ptr(), d2.data_ptr(), _stream()), "groupnorm_bwd_cat")
+        if deferred:        # per-strip channel partials follow the group partials in scratch
+            strips = nsc // (B * (2 * G + 2 * C))
+            _REDUCE_QUEUE.push(scratch.data_ptr() + 4 * B * strips * G * 2, db, dg, B * strips, 2 * C, C, scratch)
+        # shortcut weight / bias gradients
+        dw = dbias = None
+        want_db = ctx.has_bias and needs[9]
+        if needs[10]:
+            assert pack.grad_out is not None, "CatNormShortcutFn: the weight gradient needs its preassigned buffer"
+            if want_db and pack.bias_grad_out is None:
+                dbias = torch.zeros(pack.n, dtype=F32, device=dy.device)
+            dbp = (pack.bias_grad_out if pack.bias_grad_out is not None else dbias) if want_db else None
+            if _WGRAD_QUEUE is not None:
+                _WGRAD_QUEUE.push_cat(dr2, x1.view(-1, C1), x2.view(-1, C2), pack.grad_out, dbp, pack.on_grad_ready)
+            else:           # no deferred queue: the single-job entry point has no two-source form
+                wgrad(dr2, torch.cat([x1.view(-1, C1), x2.view(-1, C2)], 1), C, pack.n, out=pack.grad_out, accumulate=2, dbias=dbp)
+                if pack.on_grad_ready is not None:
+                    pack.on_grad_ready()
+        elif want_db:
+            dbias = colsum(dr2)[0]
+        gg, gb = (None, None) if (direct or frozen) else (dg, db)
+        return dx1, dx2, gg, gb, None, None, None, None, None, dbias, dw
+
+
+def cat_train_ready(pack, weight):
+    """CatNormShortcutFn can produce the weight gradient of this shortcut (or none is wanted)."""
+    return (not weight.requires_grad) or pack.grad_out is not None
 
 
 class GroupNormFn(torch.autograd.Function):

@@ -28,8 +28,8 @@ import torch.nn as nn
 
 from ._lib import lib, check
 from . import ops
-from .ops import (BF16, F32, AttentionFn, ConvFn, GegluFn, GegluLinearFn, GroupNormFn, LayerNormFn, LinearFn, SiluF32ToBf16Fn,
-                  SplitColsFn, ToNCHWFn, ToNHWCFn, WeightPack, _stream)
+from .ops import (BF16, F32, AttentionFn, CatNormShortcutFn, ConvFn, GegluFn, GegluLinearFn, GroupNormFn, LayerNormFn, LinearFn,
+                  SiluF32ToBf16Fn, SplitColsFn, ToNCHWFn, ToNHWCFn, WeightPack, _stream)
 
 
 @dataclass
@@ -182,9 +182,29 @@ class ResnetBlock(nn.Module):
         B, H, W, C1 = x1.shape
         C2 = x2.shape[-1]
         w = sc.pack.w16.view(sc.pack.cout, C1 + C2)
-        res = ops.gemm(x1.view(-1, C1), w[:, :C1], bias=sc.bias)
-        res = ops.gemm(x2.view(-1, C2), w[:, C1:], residual=res, out=res)
+        if C1 % 64 == 0 and C2 % 64 == 0 and sc.pack.cout % 160 == 0:
+            res = ops.gemm_cat(x1.view(-1, C1), x2.view(-1, C2), w, bias=sc.bias)       # one product, both sources in place
+        else:
+            res = ops.gemm(x1.view(-1, C1), w[:, :C1], bias=sc.bias)
+            res = ops.gemm(x2.view(-1, C2), w[:, C1:], residual=res, out=res)
         return self.conv2(h, residual=res.view(B, H, W, -1))
+
+    def forward_cat_train(self, x1, x2, temb_act):
+        """The same with autograd: the two input gradients leave as separate tensors (ops.CatNormShortcutFn)."""
+        n1, sc = self.norm1, self.conv_shortcut
+        h, res = CatNormShortcutFn.apply(x1, x2, n1.weight, n1.bias, n1.num_groups, n1.eps, True, n1.grad_dst, sc.pack,
+                                         sc.bias, sc.weight)
+        rb = self._tproj if self._tproj is not None else self.time_emb_proj(temb_act, out_fp32=True)
+        h = self.conv1(h, rowbias=rb)
+        h = self.norm2(h, silu=True)
+        return self.conv2(h, residual=res)
+
+    def cat_train_ready(self, x1, x2):
+        sc = self.conv_shortcut
+        return (torch.is_grad_enabled() and sc is not None and sc.kernel_size == 1 and not sc.padded
+                and x1.shape[-1] % 160 == 0 and x2.shape[-1] % 8 == 0 and x1.is_contiguous() and x2.is_contiguous()
+                and x1.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+                and ops.cat_train_ready(sc.pack, sc.weight) and os.environ.get("MI355_NO_CAT_FUSION") != "1")
 
     def cat_ready(self, x1, x2):
         sc = self.conv_shortcut
@@ -406,6 +426,8 @@ class UpBlock(nn.Module):
             skip = skips.pop()
             if r.cat_ready(x, skip):
                 x = r.forward_cat(x, skip, temb)
+            elif r.cat_train_ready(x, skip):
+                x = r.forward_cat_train(x, skip, temb)
             else:
                 x = r(torch.cat([x, skip], dim=-1), temb)
             if self.attentions is not None:

@@ -78,6 +78,18 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
                     const void* residual, int ldr, float alpha, const float* lora_t, int lora_ldt, const float* lora_b, int lora_r,
                     int lora_seg, int lora_rmajor, int lora_t_bf16, float lora_alpha, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* The same product on a column-concatenated input read in place, and with a column-split output - the 1x1 shortcut
+ * convolution of the up-path residual blocks, whose input is hidden state | skip connection (the
+ * `torch.cat([hidden_states, res_hidden_states], dim=1)` of the third-party up block the reference calls at
+ * image_generator.py:93-95), forward and data gradient, without building the concatenation:
+ *   mi355_gemm_cat_bf16:   out [M][N] = [A1 | A2] Bw^T + bias; A1 [M][K1], A2 [M][K2] contiguous, Bw [N][K1 + K2] (row
+ *                          stride ldb); K1, K2 multiples of 64, N of 160.
+ *   mi355_gemm_split_bf16: [out1 | out2] = A Bw^T as two tensors, out1 [M][N1], out2 [M][N2]; Bw [N1 + N2][K]; N1 a
+ *                          multiple of 320, N2 of 8. */
+int mi355_gemm_cat_bf16(const void* A1, int K1, const void* A2, int K2, const void* Bw, int ldb, int M, int N, void* out,
+                        int ldo, const float* bias, void* workspace, size_t workspace_bytes, void* stream);
+int mi355_gemm_split_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N1, int N2, int K, void* out1,
+                          void* out2, void* workspace, size_t workspace_bytes, void* stream);
 
 /* 3x3 stride-2 convolution with one pixel of zero padding on the bottom and right only (the AutoencoderKL
  * down-sampler reached through image_generator.py:107-108 `self.vae.encode`): x [B][H][W][C] -> out [B][H/2][W/2][Cout]. */
@@ -126,6 +138,12 @@ int mi355_wgrad_sumsq_slots(void);
 int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* dw, float* dbias, int B, int H, int W,
                          int Cin, int Cout, int ksize, int stride, int ups, int Ho, int Wo, int first_block,
                          int* splits_out, float* sumsq_slots, void* dw_bf16);
+/* The job of a dense layer whose input is the channel concatenation [x1 | x2] (x1 [M][C1], x2 [M][C2]) read in place:
+ * dw [Cout][C1 + C2] as if the concatenation had been built (the 1x1 shortcut of the up-path residual blocks, whose
+ * input is hidden state | skip connection - image_generator.py:93-95 through the third-party up block).  C1 must be a
+ * multiple of 160, C2 of 8.  Other arguments and the return value as for mi355_wgrad_job_fill. */
+int mi355_wgrad_job_fill_cat(void* host_job, const void* dy, const void* x1, int C1, const void* x2, int C2, float* dw,
+                             float* dbias, int M, int Cout, int first_block, int* splits_out, float* sumsq_slots, void* dw_bf16);
 int mi355_wgrad_grouped(const void* jobs, int njobs, int total_blocks, double flops, void* stream);
 
 /* out[s][n] = sum of the rows of segment s (seg rows each) of y[M][N] (bias / broadcast gradients). */
@@ -176,6 +194,13 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
  * image_generator.py:93-95).  y [B][HW][C1 + C2]; stats and scratch as for mi355_groupnorm_fwd with C = C1 + C2. */
 int mi355_groupnorm_fwd_cat(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta, void* y,
                             float* stats, float* scratch, int B, int HW, int G, float eps, int silu, void* stream);
+/* Backward of mi355_groupnorm_fwd_cat: x1 / x2 as in the forward call, dy [B][HW][C1 + C2]; the input gradient is written
+ * as two tensors, dx1 [B][HW][C1] and dx2 [B][HW][C2], and dres1 / dres2 (optional, both or neither; shapes of x1 / x2)
+ * are added to them in the same pass.  dgamma / dbeta [C1 + C2] or both NULL; scratch as for mi355_groupnorm_bwd with
+ * C = C1 + C2 (the deferred parameter-gradient reduction of mi355_reduce_rows_batched applies unchanged). */
+int mi355_groupnorm_bwd_cat(const void* x1, int C1, const void* x2, int C2, const void* dy, const float* stats,
+                            const float* gamma, const float* beta, void* dx1, void* dx2, float* dgamma, float* dbeta,
+                            float* scratch, int B, int HW, int G, int silu, const void* dres1, const void* dres2, void* stream);
 /* mi355_groupnorm_fwd without a scratch argument, for callers that cannot allocate device memory (code under HIP graph
  * capture, serving loops and harnesses that forbid hipMalloc).  No counterpart in the reference.  The strips' partial
  * sums live in a 1 MiB device array built into the library (one copy per GPU, held until the process ends), so the

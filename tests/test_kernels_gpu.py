@@ -681,3 +681,183 @@ def test_up_path_resnet_without_the_concatenation():
         got = blk.forward_cat(x1, x2, temb)
         want = blk(torch.cat([x1, x2], -1), temb)
     assert rel_l2(got, want.float()) < 4e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 640, 320), (3, 16, 16, 1280, 640), (2, 8, 8, 1280, 1280), (2, 4, 4, 1280, 1280),
+                                   (2, 8, 8, 1280, 640), (2, 16, 16, 640, 640)])
+def test_groupnorm_backward_on_two_sources(shape):
+    """mi355_groupnorm_bwd_cat against mi355_groupnorm_bwd on the materialised concatenation (with a bypass gradient and
+    parameter gradients): the same kernels, the same sums in the same order - input gradients equal bit for bit as the two
+    column blocks of the reference's, on the strip kernels and on the small-map kernel."""
+    from image_generator_amd.ops import lib, check, _stream
+    d = dev()
+    B, H, W, C1, C2 = shape
+    C, G, HW = C1 + C2, 32, H * W
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x1 = (torch.randn(B, H, W, C1, generator=g) * 1.5 + 0.3).to(BF).to(d)
+    x2 = (torch.randn(B, H, W, C2, generator=g) * 0.7 - 0.2).to(BF).to(d)
+    dy = torch.randn(B, H, W, C, generator=g).to(BF).to(d)
+    r1 = torch.randn(B, H, W, C1, generator=g).to(BF).to(d)
+    r2 = torch.randn(B, H, W, C2, generator=g).to(BF).to(d)
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1).to(d)
+    beta = (torch.randn(C, generator=g) * 0.1).to(d)
+    xc, rc = torch.cat([x1, x2], -1), torch.cat([r1, r2], -1)
+    nsc = int(lib.mi355_groupnorm_scratch_floats(B, HW, C, G))
+    for silu in (1, 0):
+        y = torch.empty_like(xc)
+        stats = torch.empty(B, G, 2, device=d)
+        sc = torch.empty(nsc, device=d)
+        check(lib.mi355_groupnorm_fwd(xc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                      sc.data_ptr(), B, HW, C, G, 1e-5, silu, _stream()))
+        for with_res in (True, False):
+            dx = torch.empty_like(xc)
+            dg, db = torch.empty(C, device=d), torch.empty(C, device=d)
+            check(lib.mi355_groupnorm_bwd(xc.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          dx.data_ptr(), dg.data_ptr(), db.data_ptr(), sc.data_ptr(), B, HW, C, G, silu,
+                                          rc.data_ptr() if with_res else None, _stream()))
+            dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+            dg2, db2 = torch.empty(C, device=d), torch.empty(C, device=d)
+            check(lib.mi355_groupnorm_bwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, dy.data_ptr(), stats.data_ptr(),
+                                              gamma.data_ptr(), beta.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), dg2.data_ptr(),
+                                              db2.data_ptr(), sc.data_ptr(), B, HW, G, silu,
+                                              r1.data_ptr() if with_res else None, r2.data_ptr() if with_res else None, _stream()))
+            assert torch.equal(dx1, dx[..., :C1]) and torch.equal(dx2, dx[..., C1:])
+            assert torch.equal(dg2, dg) and torch.equal(db2, db)
+    # one bypass gradient without the other is refused
+    assert lib.mi355_groupnorm_bwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
+                                       beta.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), None, None, sc.data_ptr(), B, HW, G, 1,
+                                       r1.data_ptr(), None, _stream()) != 0
+
+
+@pytest.mark.parametrize("case", [(512, 320, 320, 320), (2048, 1280, 640, 640), (32768, 640, 320, 320), (300, 160, 8, 48)])
+def test_weight_gradient_job_on_two_sources(case):
+    """The deferred dense weight-gradient job that reads [x1 | x2] in place (mi355_wgrad_job_fill_cat) against the job on
+    the materialised concatenation: equal bit for bit when the job is not pixel-split (same tiles, same order), to
+    accumulation order when it is; a C1 that is not a multiple of the 160-channel tile is refused."""
+    import ctypes
+    from image_generator_amd.ops import lib, WgradQueue
+    d = dev()
+    M, C1, C2, Co = case
+    g = torch.Generator().manual_seed(M + C1)
+    x1 = torch.randn(M, C1, generator=g).to(BF).to(d)
+    x2 = torch.randn(M, C2, generator=g).to(BF).to(d)
+    dy = torch.randn(M, Co, generator=g).to(BF).to(d)
+    xc = torch.cat([x1, x2], -1)
+    want, got = torch.zeros(Co, C1 + C2, device=d), torch.zeros(Co, C1 + C2, device=d)
+    dbw, dbg = torch.zeros(Co, device=d), torch.zeros(Co, device=d)
+    q = WgradQueue(d)
+    q.push(dy, xc, want, dbw, M, 1, 1, C1 + C2, Co, 1, 1, False, 1, 1)
+    split = q._splits.value > 1
+    q.push_cat(dy, x1, x2, got, dbg)
+    assert (q._splits.value > 1) == split
+    q.join()
+    torch.cuda.synchronize()
+    assert float(want.abs().max()) > 0
+    if split:
+        close(got, want, 1e-4, 1e-4 * float(want.abs().max()), "split two-source wgrad")
+    else:
+        assert torch.equal(got, want)
+    close(dbg, dbw, 1e-4, 1e-3, "two-source wgrad bias gradient")
+    ref = dy.float().t() @ xc.float()
+    close(got, ref, 2e-2, 2e-2 * float(ref.abs().max()), "two-source wgrad vs fp32")
+    host = (ctypes.c_char * int(lib.mi355_wgrad_job_bytes()))()
+    assert lib.mi355_wgrad_job_fill_cat(host, dy.data_ptr(), x1.data_ptr(), 80, x2.data_ptr(), C2, got.data_ptr(), None, M, Co, 0,
+                                        None, None, None) < 0
+
+
+def test_up_path_resnet_trains_without_the_concatenation():
+    """ResnetBlock.forward_cat_train (ops.CatNormShortcutFn: two-source normalisation forward and backward, split shortcut,
+    one two-source weight-gradient job) against the block on torch.cat([hidden, skip]) in the trainer's gradient mode
+    (gradients written into preassigned buffers through the deferred queues): output, both input gradients and every
+    parameter gradient."""
+    import image_generator_amd.unet as U
+    from image_generator_amd import ops
+    d = dev()
+    torch.manual_seed(5)
+    blk = U.ResnetBlock(640 + 320, 320, 1280, 32, 1e-5).to(d)
+    layers = [m for m in blk.modules() if isinstance(m, (U.HipConv2d, U.HipLinear))]
+    norms = [m for m in blk.modules() if isinstance(m, U.HipGroupNorm)]
+    for m in layers:        # a stand-alone block has no flat storage: operand copies and gradient views as the model makes them
+        pk = m.pack
+        if isinstance(m, U.HipConv2d):
+            t = pk.ksize * pk.ksize
+            pk.w16 = m.weight.data.permute(0, 2, 3, 1).reshape(pk.cout, t, pk.cin).to(BF).contiguous()
+            pk.w16_t = pk.w16.view(pk.cout, t * pk.cin).t().contiguous() if t == 1 else \
+                m.weight.data.flip(2, 3).permute(1, 2, 3, 0).reshape(pk.cin, t, pk.cout).to(BF).contiguous()
+        else:
+            pk.w16 = m.weight.data.to(BF).contiguous()
+            pk.w16_t = pk.w16.t().contiguous()
+    x1 = rnd(2, 16, 16, 640, seed=51).to(d)
+    x2 = rnd(2, 16, 16, 320, seed=52).to(d)
+    temb = rnd(2, 1280, seed=53).to(d)
+    dout = rnd(2, 16, 16, 320, seed=54).to(d)
+
+    def run(fused):
+        for m in layers:
+            m.pack.grad_out = torch.zeros(m.pack.n, m.pack.k, device=d)
+            m.pack.bias_grad_out = torch.zeros(m.pack.n, device=d)
+        for n in norms:
+            n.grad_dst = (torch.zeros_like(n.weight), torch.zeros_like(n.bias))
+        q, rq = ops.WgradQueue(d), ops.ReduceQueue(d)
+        ops.set_wgrad_queue(q)
+        ops.set_reduce_queue(rq)
+        try:
+            a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+            if fused:
+                assert blk.cat_train_ready(a, b)
+                out = blk.forward_cat_train(a, b, temb)
+            else:
+                out = blk(torch.cat([a, b], -1), temb)
+            out.backward(dout)
+            q.join()
+            rq.flush()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_wgrad_queue(None)
+            ops.set_reduce_queue(None)
+        grads = [m.pack.grad_out for m in layers] + [m.pack.bias_grad_out for m in layers] + [t for n in norms for t in n.grad_dst]
+        return out.detach(), a.grad, b.grad, grads
+
+    o0, a0, b0, g0 = run(False)
+    o1, a1, b1, g1 = run(True)
+    assert rel_l2(o1, o0.float()) < 4e-3
+    assert rel_l2(a1, a0.float()) < 1e-2 and rel_l2(b1, b0.float()) < 1e-2
+    for i, (u, v) in enumerate(zip(g1, g0)):
+        if float(v.abs().max()) > 0:
+            assert rel_l2(u, v) < 1e-2, i
+        else:
+            assert float(u.abs().max()) == 0, i
+
+
+@pytest.mark.parametrize("case", [(32768, 640, 320, 320), (8192, 1280, 640, 640), (2048, 1280, 1280, 1280), (512, 1280, 1280, 1280),
+                                  (300, 64, 128, 160)])
+def test_gemm_on_two_sources_and_into_two_destinations(case):
+    """mi355_gemm_cat_bf16 ([a1 | a2] W^T + b with the concatenation read in place) and mi355_gemm_split_bf16 (column
+    blocks of a product written as two tensors) against mi355_gemm_bf16 on the materialised concatenation / output:
+    the same tiles and k order, so equal bit for bit - with and without split-K (the small-M cases run it)."""
+    from image_generator_amd import ops
+    d = dev()
+    M, K1, K2, N = case
+    g = torch.Generator().manual_seed(M + K1 + N)
+    a1 = torch.randn(M, K1, generator=g).to(BF).to(d)
+    a2 = torch.randn(M, K2, generator=g).to(BF).to(d)
+    w = (torch.randn(N, K1 + K2, generator=g) * (K1 + K2) ** -0.5).to(BF).to(d)
+    b = torch.randn(N, generator=g).to(d)
+    ac = torch.cat([a1, a2], 1)
+    want = ops.gemm(ac, w, bias=b)
+    got = ops.gemm_cat(a1, a2, w, bias=b)
+    assert torch.equal(got, want)
+    close(got, ac.float() @ w.float().t() + b, 2e-2, 2e-2 * float(want.float().abs().max()), "gemm_cat vs fp32")
+    if K1 % 320 == 0:
+        # data-gradient shape of the same layer: [M, N] x W -> [M, K1 | K2]
+        dy = torch.randn(M, N, generator=g).to(BF).to(d)
+        wt = w.t().contiguous()
+        full = ops.gemm(dy, wt)
+        o1, o2 = ops.gemm_split(dy, wt, K1)
+        assert torch.equal(o1, full[:, :K1]) and torch.equal(o2, full[:, K1:])
+    from image_generator_amd.ops import lib
+    ws = ops.workspace(d)
+    assert lib.mi355_gemm_cat_bf16(a1.data_ptr(), 40, a2.data_ptr(), K2, w.data_ptr(), K1 + K2, M, N, got.data_ptr(), N, None,
+                                   ws.data_ptr(), ws.numel(), None) != 0
+    assert lib.mi355_gemm_split_bf16(a1.data_ptr(), K1, w.data_ptr(), K1 + K2, M, 160, 160, K1, got.data_ptr(), got.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), None) != 0
