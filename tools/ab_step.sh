@@ -1,5 +1,5 @@
 #!/bin/bash
-# interleaved whole-step A/B on one box: base lib vs working tree
+# interleaved whole-step A/B on one box: TAGS="base new" - "new" is the library in the tree, tag T loads ab_tmp/libT.so
 R=$GRAFT_REPO_ROOT
 for i in 1 2; do
   for tag in ${TAGS:-base new}; do

@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B of attention kernels: baseline lib vs working tree, per-kernel averages from rocprofv3 for one shape at a time
+# A/B of attention kernels: per-kernel averages from rocprofv3 for one shape at a time.  TAGS="base new x": "new" is the
+# library in the tree, any other tag T loads ab_tmp/libT.so (built by tools/attn_build_variant.sh T <flags>, or a copy of
+# an older build); SHAPES="B H N D[ T];..." (default: the train step's and the 512^2 sampler's level-0 shapes).
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# build_variant.sh <tag> <extra hipcc flags...>: builds ab_tmp/lib<tag>.so from the working tree with extra flags for attention.hip
+# attn_build_variant.sh <tag> <extra hipcc flags...>: builds ab_tmp/lib<tag>.so from the working tree with extra flags for attention.hip
 tag=$1; shift
 cd /root/repo/image_generator_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form "$@" -c attention.hip -o /tmp/attention_$tag.o || exit 1

@@ -1,3 +1,4 @@
+# rocprofv3 kernel trace of a short bench.py run, per-kernel counts and averages (tools/rocpd_kernels.py); BENCH_ARGS, NLINES
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_ab; rm -rf $O; mkdir -p $O
 cd $R
