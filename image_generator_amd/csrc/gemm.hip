@@ -66,6 +66,11 @@ struct GemmArgs {
     // width, so a tile never straddles the two
     void* out2;
     int N1;
+    // GEGLU backward in the epilogue (any kernel): the product is the gradient dy [M][N = F] of the gated output
+    // y = h * gelu(g); instead of dy the epilogue writes gb_out [M][2F] = (dy * gelu(g) | dy * h * gelu'(g)) from the
+    // pre-activation gb_pre [M][2F] = (h | g) the forward pass kept
+    const bf16_t* gb_pre;
+    bf16_t* gb_out;
 };
 
 // AMODE_DENSE_LORA: dense A with the low-rank term in the epilogue - a kernel variant of its own so that every other
@@ -295,6 +300,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 const bf16x8 rv = *(const bf16x8*)(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            if (p.gb_pre != nullptr) {
+                const size_t row = (size_t)m * (2 * p.N);
+                const bf16x8 hb = *(const bf16x8*)(p.gb_pre + row + n), gb = *(const bf16x8*)(p.gb_pre + row + p.N + n);
+                bf16x8 dh, dg;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gv = (float)gb[e];
+                    dh[e] = (bf16_t)(v[e] * gelu_erf_f(gv));
+                    dg[e] = (bf16_t)(v[e] * (float)hb[e] * gelu_erf_grad_f(gv));
+                }
+                *(bf16x8*)(p.gb_out + row + n) = dh;
+                *(bf16x8*)(p.gb_out + row + p.N + n) = dg;
+                continue;
             }
             if (p.out_fp32) {
                 float* o = (float*)outp + (size_t)m * ldo + n - nsh;
@@ -1179,6 +1198,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
         }
+        if (p.gb_pre != nullptr) {           // GEGLU backward in the epilogue: see GemmArgs
+            const size_t row = (size_t)m * (2 * p.N);
+            const bf16x8 hb = *(const bf16x8*)(p.gb_pre + row + n), gb = *(const bf16x8*)(p.gb_pre + row + p.N + n);
+            bf16x8 dh, dg;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gv = (float)gb[e];
+                dh[e] = (bf16_t)(v[e] * gelu_erf_f(gv));
+                dg[e] = (bf16_t)(v[e] * (float)hb[e] * gelu_erf_grad_f(gv));
+            }
+            *(bf16x8*)(p.gb_out + row + n) = dh;
+            *(bf16x8*)(p.gb_out + row + p.N + n) = dg;
+            continue;
+        }
         char* outp = (char*)p.out;
         int ldo = p.ldo, nn = n;
         if (p.out2 != nullptr && n >= p.N1) { outp = (char*)p.out2; ldo = p.N - p.N1; nn = n - p.N1; }
@@ -1447,6 +1480,19 @@ int mi355_gemm_split_bf16(const void* A, int lda, const void* Bw, int ldb, int M
     GemmArgs a = {};
     a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N1 + N2; a.K = K; a.lda = lda; a.ldb = ldb;
     a.out = out1; a.ldo = N1; a.out2 = out2; a.N1 = N1; a.alpha = 1.f;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
+    return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// dpre [M][2F] = GEGLU backward of (dy = A Bw^T [M][F], pre [M][2F]) without writing dy: the data gradient of the
+// feed-forward output projection with the gate's backward in its epilogue.  A [M][K] (row stride lda), Bw [F][K].
+int mi355_gemm_geglu_bwd_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int F, int K, const void* pre,
+                              void* dpre, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !Bw || !pre || !dpre) return mi355_fail(MI355_ERR_ARG, "gemm_geglu_bwd: null pointer");
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = F; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.out = dpre; a.ldo = F; a.alpha = 1.f;      // (out is never written: the epilogue stores through gb_out)
+    a.gb_pre = (const bf16_t*)pre; a.gb_out = (bf16_t*)dpre;
     a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
     return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -107,6 +107,19 @@ def gemm_split(a, w, n1):
     return o1, o2
 
 
+def gemm_geglu_bwd(dout, w_t, pre):
+    """bf16 [M, 2F] = GEGLU backward of (dout[M, K] @ w_t[F, K]^T, pre[M, 2F]): the [M, F] product is never written."""
+    M, K = dout.shape
+    F = w_t.shape[0]
+    assert dout.dtype == BF16 and w_t.dtype == BF16 and pre.dtype == BF16 and dout.stride(1) == 1 and w_t.stride(1) == 1
+    assert w_t.shape[1] == K and pre.shape == (M, 2 * F) and pre.is_contiguous()
+    dpre = torch.empty_like(pre)
+    ws = workspace(dout.device)
+    check(lib.mi355_gemm_geglu_bwd_bf16(dout.data_ptr(), dout.stride(0), w_t.data_ptr(), w_t.stride(0), M, F, K, pre.data_ptr(),
+                                        dpre.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "gemm_geglu_bwd")
+    return dpre
+
+
 def gemm_skinny(a, w, alpha=1.0):
     """bf16 [M, W] = alpha * a[M, K] @ w[W, K]^T for W in (8, 16): one launch, no split-K workspace."""
     M, K = a.shape
@@ -601,6 +614,38 @@ class GegluLinearFn(torch.autograd.Function):
         n = ctx.needs_input_grad
         dx, _, db, _, _, dw = LinearFn._backward(ctx, x2, dpre, (n[0], False, n[2], False, False, n[3]))
         return dx, None, db, dw
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """The transformer feed-forward block as one node: out = (h * gelu(g)) W2^T + b2 + residual with (h | g) = x W1^T + b1.
+    Forward: the gated GEMM (pre-activation kept) and the output projection with the residual in its epilogue, as the two
+    separate nodes would.  Backward: the output projection's data gradient runs with the gate's backward in its epilogue
+    (`mi355_gemm_geglu_bwd_bf16`), so the [M][4C] gradient of the gated activations is never written or re-read."""
+
+    @staticmethod
+    def forward(ctx, x, residual, pk1, b1, w1, pk2, b2, w2):
+        from types import SimpleNamespace
+        x2 = x.reshape(-1, x.shape[-1])
+        y, pre = gemm_geglu(x2, pk1.w16.view(pk1.n, pk1.k), b1, keep_preact=True)
+        res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
+        out = gemm(y, pk2.w16.view(pk2.n, pk2.k), bias=b2, residual=res2)
+        ctx.save_for_backward(x2, pre, y)
+        ctx.c1 = SimpleNamespace(pack=pk1, xshape=x.shape, has_bias=b1 is not None, has_res=False, bshapes=[], breq=[],
+                                 wshapes=[w1.shape], wreq=[w1.requires_grad])
+        ctx.c2 = SimpleNamespace(pack=pk2, xshape=y.shape, has_bias=b2 is not None, has_res=residual is not None, bshapes=[],
+                                 breq=[], wshapes=[w2.shape], wreq=[w2.requires_grad])
+        return out.view(*x.shape[:-1], pk2.n)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, pre, y = ctx.saved_tensors
+        n = ctx.needs_input_grad            # x, residual, pk1, b1, w1, pk2, b2, w2
+        pk2 = ctx.c2.pack
+        d2 = (dout if dout.dtype == BF16 else dout.to(BF16)).reshape(-1, pk2.n).contiguous()
+        dpre = gemm_geglu_bwd(d2, pk2.w16_t.view(pk2.k, pk2.n), pre)
+        _, _, db2, dres, _, dw2 = LinearFn._backward(ctx.c2, y, d2.view(dout.shape), (False, False, n[6], n[1], False, n[7]))
+        dx, _, db1, _, _, dw1 = LinearFn._backward(ctx.c1, x2, dpre, (n[0], False, n[3], False, False, n[4]))
+        return dx, dres, None, db1, dw1, None, db2, dw2
 
 
 class SplitColsFn(torch.autograd.Function):

@@ -28,7 +28,7 @@ import torch.nn as nn
 
 from ._lib import lib, check
 from . import ops
-from .ops import (BF16, F32, AttentionFn, CatNormShortcutFn, ConvFn, GegluFn, GegluLinearFn, GroupNormFn, LayerNormFn, LinearFn,
+from .ops import (BF16, F32, AttentionFn, CatNormShortcutFn, ConvFn, FeedForwardFn, GegluFn, GegluLinearFn, GroupNormFn, LayerNormFn, LinearFn,
                   SiluF32ToBf16Fn, SplitColsFn, ToNCHWFn, ToNHWCFn, WeightPack, _stream)
 
 
@@ -308,6 +308,12 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), HipLinear(dim * 4, dim)])
 
     def forward(self, x, residual):
+        g, o = self.net[0].proj, self.net[2]
+        if (torch.is_grad_enabled() and isinstance(g, HipLinear) and isinstance(o, HipLinear) and g.pack.w16 is not None
+                and o.pack.w16 is not None and o.pack.w16_t is not None and g.pack.k % 64 == 0 and (g.pack.n // 2) % 80 == 0
+                and os.environ.get("MI355_NO_FF_FUSION") != "1"):
+            # training: one autograd node, the gate's backward rides the output projection's data-gradient GEMM
+            return FeedForwardFn.apply(x, residual, g.pack, g.bias, g.weight, o.pack, o.bias, o.weight)
         return self.net[2](self.net[0](x), residual=residual)
 
 

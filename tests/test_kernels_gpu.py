@@ -861,3 +861,70 @@ def test_gemm_on_two_sources_and_into_two_destinations(case):
                                    ws.data_ptr(), ws.numel(), None) != 0
     assert lib.mi355_gemm_split_bf16(a1.data_ptr(), K1, w.data_ptr(), K1 + K2, M, 160, 160, K1, got.data_ptr(), got.data_ptr(),
                                      ws.data_ptr(), ws.numel(), None) != 0
+
+
+@pytest.mark.parametrize("case", [(32768, 320, 1280), (8192, 640, 2560), (2048, 1280, 5120), (512, 1280, 5120), (200, 64, 80)])
+def test_geglu_backward_in_the_gemm_epilogue(case):
+    """mi355_gemm_geglu_bwd_bf16 (data gradient of the feed-forward output projection with the gate's backward in its
+    epilogue) against the two separate steps: the fused form applies the gate's derivative to the fp32 accumulator, the
+    separate one to the product rounded to bf16 first - equal to that rounding; and against fp32 math."""
+    from image_generator_amd import ops
+    from image_generator_amd.ops import lib, check, _stream
+    d = dev()
+    M, C, F = case
+    g = torch.Generator().manual_seed(M + F)
+    dout = torch.randn(M, C, generator=g).to(BF).to(d)
+    w_t = (torch.randn(F, C, generator=g) * C ** -0.5).to(BF).to(d)          # [F][C]: the projection's weight transposed
+    pre = torch.randn(M, 2 * F, generator=g).to(BF).to(d)
+    got = ops.gemm_geglu_bwd(dout, w_t, pre)
+    dy = ops.gemm(dout, w_t)
+    want = torch.empty_like(pre)
+    check(lib.mi355_geglu_bwd(pre.data_ptr(), dy.data_ptr(), want.data_ptr(), M, F, _stream()))
+    assert rel_l2(got, want.float()) < 4e-3
+    dyf = dout.float() @ w_t.float().t()
+    h, gt = pre[:, :F].float(), pre[:, F:].float()
+    gelu = torch.nn.functional.gelu(gt)
+    dgelu = 0.5 * (1 + torch.erf(gt / 2 ** 0.5)) + gt * torch.exp(-0.5 * gt * gt) / (2 * torch.pi) ** 0.5
+    ref = torch.cat([dyf * gelu, dyf * h * dgelu], 1)
+    assert rel_l2(got, ref) < 6e-3
+
+
+def test_feed_forward_block_as_one_node():
+    """unet.FeedForward in training mode (ops.FeedForwardFn: the gate's backward inside the output projection's
+    data-gradient GEMM) against the two separate nodes (MI355_NO_FF_FUSION=1): output bit-equal, input / residual /
+    parameter gradients equal to the bf16 rounding of the gated activations' gradient."""
+    import os
+    import image_generator_amd.unet as U
+    d = dev()
+    torch.manual_seed(7)
+    ff = U.FeedForward(320).to(d)
+    for m in ff.modules():
+        if isinstance(m, U.HipLinear):
+            m.pack.w16 = m.weight.data.to(BF).contiguous()
+            m.pack.w16_t = m.pack.w16.t().contiguous()
+    x = rnd(2, 256, 320, seed=61).to(d)
+    res = rnd(2, 256, 320, seed=62).to(d)
+    dout = rnd(2, 256, 320, seed=63).to(d)
+
+    def run(fused):
+        if fused:
+            os.environ.pop("MI355_NO_FF_FUSION", None)
+        else:
+            os.environ["MI355_NO_FF_FUSION"] = "1"
+        try:
+            for p in ff.parameters():
+                p.grad = None
+            a, r = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+            out = ff(a, r)
+            out.backward(dout)
+            torch.cuda.synchronize()
+            return out.detach(), a.grad, r.grad, [p.grad.clone() for p in ff.parameters()]
+        finally:
+            os.environ.pop("MI355_NO_FF_FUSION", None)
+
+    o0, a0, r0, g0 = run(False)
+    o1, a1, r1, g1 = run(True)
+    assert torch.equal(o1, o0) and torch.equal(r1, r0)
+    assert rel_l2(a1, a0.float()) < 5e-3
+    for u, v in zip(g1, g0):
+        assert rel_l2(u, v.float()) < 5e-3
