@@ -199,13 +199,18 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
     for (; r < r_end; r += rpar) apply(*(const bf16x8*)(xs + (size_t)r * ldx), r);
 }
 
+// SUMS: the block also leaves the column sums of the dx rows it wrote in dxsum [B][strips][C] (the values as stored, i.e.
+// rounded to bf16): per sample they are the gradient of a per-sample bias that the producer of x added (the
+// timestep-embedding projection in the first convolution of a residual block), which then needs no pass of its own.
+template <bool SUMS = false>
 __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                     const float* __restrict__ stats, const float* __restrict__ gpart,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     bf16_t* __restrict__ dx, int HW, int C, int G, int rows_per_block, int silu,
                                     const bf16_t* __restrict__ dres, const bf16_t* __restrict__ x2 = nullptr, int C1 = 0,
-                                    bf16_t* __restrict__ dx2 = nullptr, const bf16_t* __restrict__ dres2 = nullptr) {
-    extern __shared__ float gs[];            // [G][2] = {sum_c gamma*sum dz, sum_c gamma*sum dz*xhat}
+                                    bf16_t* __restrict__ dx2 = nullptr, const bf16_t* __restrict__ dres2 = nullptr,
+                                    float* __restrict__ dxsum = nullptr) {
+    extern __shared__ float gs[];            // [G][2] = {sum_c gamma*sum dz, sum_c gamma*sum dz*xhat} (+ SUMS: [threads][8])
     const int nc = C >> 3;
     const int b = blockIdx.y;
     gn_group_sums(gpart, gs, b, gridDim.x, G);
@@ -238,6 +243,7 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
         if (c8 * 8 < C1) { ldx = C1; } else { xs = x2; rsrc = dres2; ds = dx2; off = (size_t)(c8 * 8 - C1); ldx = C - C1; }
     }
     off += (size_t)b * HW * ldx;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto apply = [&](const bf16x8& xv, const bf16x8& dv, int r) {
         bf16x8 ov;
 #pragma unroll
@@ -251,6 +257,10 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
             const bf16x8 rv = *(const bf16x8*)(rsrc + off + (size_t)r * ldx);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)((float)ov[e] + (float)rv[e]);
+        }
+        if (SUMS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += (float)ov[e];
         }
         *(bf16x8*)(ds + off + (size_t)r * ldx) = ov;
     };
@@ -267,6 +277,23 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
     }
     for (; r < r_end; r += rpar)
         apply(*(const bf16x8*)(xs + off + (size_t)r * ldx), *(const bf16x8*)(dy + base + (size_t)r * C), r);
+    if (SUMS) {                              // row phases of the block combined through LDS, one partial row per block
+        float* red = gs + 2 * G;
+        float* mine = red + ((size_t)rp * nc + c8) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mine[e] = cs[e];
+        __syncthreads();
+        if (rp == 0) {
+            for (int q = 1; q < rpar; ++q) {
+                const float* o = red + ((size_t)q * nc + c8) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] += o[e];
+            }
+            float* dst = dxsum + ((size_t)b * gridDim.x + blockIdx.x) * C + c8 * 8;
+            *(f32x4*)dst = f32x4{cs[0], cs[1], cs[2], cs[3]};
+            *(f32x4*)(dst + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -352,8 +379,11 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const bf16_t* __restr
                                                            int HW, int C, int G, int silu,
                                                            const bf16_t* __restrict__ x2 = nullptr, int C1 = 0,
                                                            bf16_t* __restrict__ dx2 = nullptr,
-                                                           const bf16_t* __restrict__ dres2 = nullptr) {
-    extern __shared__ float pc[];            // [chunk][16]: 8 x dz, 8 x dz*xhat per chunk (parameter gradients only)
+                                                           const bf16_t* __restrict__ dres2 = nullptr,
+                                                           float* __restrict__ dxsum = nullptr) {
+    // dxsum (optional): [B][C] column sums of the sample's dx rows as stored (see gn_bwd_apply_kernel<true>)
+    extern __shared__ float pc[];            // [chunk][16]: 8 x dz, 8 x dz*xhat per chunk (parameter gradients only);
+                                             // then [chunk][8]: the dx values (dxsum only)
     __shared__ float red[2][16];
     const int g = blockIdx.x, b = blockIdx.y, cg = C / G, ncc = cg >> 3, n = HW * ncc;
     const size_t base = (size_t)b * HW * C + (size_t)g * cg;
@@ -415,7 +445,21 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)o[e] + (float)rv[e]);
             }
+            if (dxsum) {
+                float* q = pc + (size_t)n * 16 + (size_t)idx * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = (float)o[e];
+            }
             *(bf16x8*)(ddst + doff) = o;
+        }
+    }
+    if (dxsum) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < cg; t += 256) {
+            const int cc = t >> 3, e = t & 7;
+            float acc = 0.f;
+            for (int r = 0; r < HW; ++r) acc += pc[(size_t)n * 16 + (size_t)(r * ncc + cc) * 8 + e];
+            dxsum[(size_t)b * C + g * cg + t] = acc;
         }
     }
     if (cpart) {
@@ -683,20 +727,23 @@ int mi355_groupnorm_fwd_static(const void* x, const float* gamma, const float* b
     return mi355_groupnorm_fwd(x, gamma, beta, y, stats, scratch, B, HW, C, G, eps, silu, stream);
 }
 
+// dx_colsum (optional, with colsum_scratch of mi355_groupnorm_scratch_floats() floats): [B][C] per-sample column sums of dx
 static int gn_bwd_launch(const void* x, const void* x2, int C1, const void* dy, const float* stats, const float* gamma,
                          const float* beta, void* dx, void* dx2, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C,
-                         int G, int silu, const void* dres, const void* dres2, void* stream) {
+                         int G, int silu, const void* dres, const void* dres2, void* stream, float* dx_colsum = nullptr,
+                         float* colsum_scratch = nullptr) {
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
     hipStream_t st = (hipStream_t)stream;
     float* gpart = scratch;
     float* cpart = scratch + (size_t)B * strips * G * 2;
     ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 5);
-    if (gn_small(HW, C, G)) {
-        const size_t shs = (size_t)HW * (C / G / 8) * 16 * sizeof(float);
+    const size_t shs_small = (size_t)HW * (C / G / 8) * (dx_colsum ? 24 : 16) * sizeof(float);
+    if (gn_small(HW, C, G) && shs_small <= 64 * 1024) {
+        const size_t shs = shs_small;
         hipLaunchKernelGGL(gn_small_bwd_kernel, dim3(G, B), dim3(256), shs, st, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma,
                            beta, (bf16_t*)dx, cpart, (const bf16_t*)dres, HW, C, G, silu, (const bf16_t*)x2, C1, (bf16_t*)dx2,
-                           (const bf16_t*)dres2);
+                           (const bf16_t*)dres2, dx_colsum);
         if (dgamma)
             hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B, 2 * C, dgamma, C);
         return mi355_check_launch("groupnorm_bwd(small)");
@@ -704,9 +751,17 @@ static int gn_bwd_launch(const void* x, const void* x2, int C1, const void* dy, 
     const size_t sh = (size_t)threads * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x,
                        (const bf16_t*)dy, stats, gamma, beta, gpart, cpart, HW, C, G, rows, silu, (const bf16_t*)x2, C1);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st,
-                       (const bf16_t*)x, (const bf16_t*)dy, stats, gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu,
-                       (const bf16_t*)dres, (const bf16_t*)x2, C1, (bf16_t*)dx2, (const bf16_t*)dres2);
+    if (dx_colsum) {
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(strips, B), dim3(threads),
+                           ((size_t)G * 2 + (size_t)threads * 8) * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)dy, stats,
+                           gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu, (const bf16_t*)dres, (const bf16_t*)x2, C1,
+                           (bf16_t*)dx2, (const bf16_t*)dres2, colsum_scratch);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, colsum_scratch, dx_colsum, strips, C);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st,
+                           (const bf16_t*)x, (const bf16_t*)dy, stats, gpart, gamma, beta, (bf16_t*)dx, HW, C, G, rows, silu,
+                           (const bf16_t*)dres, (const bf16_t*)x2, C1, (bf16_t*)dx2, (const bf16_t*)dres2);
+    }
     // dbeta = column sums of the first plane, dgamma of the second (skipped for frozen affine parameters)
     if (dgamma)
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 63) / 64, 1), dim3(256), 0, st, cpart, dbeta, B * strips, 2 * C, dgamma, C);
@@ -721,6 +776,17 @@ int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const
         return mi355_fail(MI355_ERR_ARG, "groupnorm_bwd: null pointer");
     return gn_bwd_launch(x, nullptr, 0, dy, stats, gamma, beta, dx, nullptr, dgamma, dbeta, scratch, B, HW, C, G, silu, dres,
                          nullptr, stream);
+}
+
+// mi355_groupnorm_bwd that also returns dx_colsum [B][C] = per-sample column sums of the dx it stores (the gradient of a
+// per-sample bias added by the producer of x); colsum_scratch: another mi355_groupnorm_scratch_floats() floats.
+int mi355_groupnorm_bwd_colsum(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                               void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
+                               const void* dres, float* dx_colsum, float* colsum_scratch, void* stream) {
+    if (!x || !dy || !stats || !gamma || !beta || !dx || !scratch || (!dgamma != !dbeta) || !dx_colsum || !colsum_scratch)
+        return mi355_fail(MI355_ERR_ARG, "groupnorm_bwd_colsum: null pointer");
+    return gn_bwd_launch(x, nullptr, 0, dy, stats, gamma, beta, dx, nullptr, dgamma, dbeta, scratch, B, HW, C, G, silu, dres,
+                         nullptr, stream, dx_colsum, colsum_scratch);
 }
 
 // Backward of mi355_groupnorm_fwd_cat: the input gradient leaves as two tensors shaped like x1 and x2.

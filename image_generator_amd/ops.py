@@ -687,6 +687,7 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         pack, stride, ups = ctx.pack, ctx.stride, ctx.ups
+        pre_sums = _DX_COLSUMS.pop(dy.data_ptr(), None)      # left by the GroupNorm backward that produced dy, if any
         if dy.dtype != BF16:
             dy = dy.to(BF16)
         dy = dy.contiguous()
@@ -730,7 +731,10 @@ class ConvFn(torch.autograd.Function):
         if want_db and not direct_b:
             db = (dbp if dbp is not None else colsum(dy2)[0])[:pack.cout]
         if ctx.flags[1] and ctx.needs_input_grad[3]:
-            drb = colsum(dy2, seg=Ho * Wo)
+            if pre_sums is not None and pre_sums.shape == (B, Co):
+                drb = pre_sums
+            else:
+                drb = colsum(dy2, seg=Ho * Wo)
         if ctx.flags[2] and ctx.needs_input_grad[4]:
             dres = dy
         return dx, dw, db, drb, dres, None, None, None, None
@@ -835,9 +839,14 @@ def cat_train_ready(pack, weight):
     return (not weight.requires_grad) or pack.grad_out is not None
 
 
+# per-sample column sums of an input gradient that a GroupNorm backward produced along with it, keyed by the gradient's
+# address: the convolution whose output that norm read takes its per-sample bias gradient from here (ConvFn.backward)
+_DX_COLSUMS = {}
+
+
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu, gdst=None, passthrough=False):
+    def forward(ctx, x, gamma, beta, groups, eps, silu, gdst=None, passthrough=False, colsum=False):
         """gdst: optional (dgamma, dbeta) fp32 views the parameter gradients are written into directly.
         passthrough: also return x itself, for the branch that reads x beside the norm (residual / shortcut);
         backward then adds that branch's gradient inside the normalisation kernel instead of a separate add."""
@@ -849,6 +858,9 @@ class GroupNormFn(torch.autograd.Function):
                                       scratch.data_ptr(), B, H * W, C, groups, eps, int(silu), _stream()), "groupnorm_fwd")
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.groups, ctx.silu, ctx.gdst = groups, silu, gdst
+        # colsum: x is the output of a convolution with a per-sample bias; backward leaves that bias's gradient (the
+        # per-sample column sums of dx) in _DX_COLSUMS for the convolution's backward
+        ctx.colsum = colsum
         if passthrough:
             return y, x.view_as(x)
         return y
@@ -868,15 +880,25 @@ class GroupNormFn(torch.autograd.Function):
         nsc = int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, G))
         scratch = torch.empty(nsc, dtype=F32, device=x.device)
         deferred = direct and not frozen and _REDUCE_QUEUE is not None
-        check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                      dx.data_ptr(), None if deferred else _ptr(dg), None if deferred else _ptr(db),
-                                      scratch.data_ptr(), B, H * W, C, G, int(ctx.silu), _ptr(dpass), _stream()), "groupnorm_bwd")
+        if ctx.colsum:
+            sums = torch.empty((B, C), dtype=F32, device=x.device)
+            sc2 = torch.empty(nsc, dtype=F32, device=x.device)
+            check(lib.mi355_groupnorm_bwd_colsum(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                 dx.data_ptr(), None if deferred else _ptr(dg), None if deferred else _ptr(db),
+                                                 scratch.data_ptr(), B, H * W, C, G, int(ctx.silu), _ptr(dpass), sums.data_ptr(),
+                                                 sc2.data_ptr(), _stream()), "groupnorm_bwd_colsum")
+            _DX_COLSUMS.clear()             # at most one pending entry: the producing convolution's backward runs next
+            _DX_COLSUMS[dx.data_ptr()] = sums
+        else:
+            check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          dx.data_ptr(), None if deferred else _ptr(dg), None if deferred else _ptr(db),
+                                          scratch.data_ptr(), B, H * W, C, G, int(ctx.silu), _ptr(dpass), _stream()), "groupnorm_bwd")
         if deferred:        # per-strip channel partials follow the group partials in scratch
             strips = nsc // (B * (2 * G + 2 * C))
             _REDUCE_QUEUE.push(scratch.data_ptr() + 4 * B * strips * G * 2, db, dg, B * strips, 2 * C, C, scratch)
         if direct or frozen:
-            return dx, None, None, None, None, None, None, None
-        return dx, dg, db, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -60,6 +60,10 @@ class DenoiserConfig:
         return self.block_out_channels[0] * 4
 
 
+# the first convolution's per-sample bias gradient comes out of the second normalisation's backward kernel
+_COLSUM_FUSION = os.environ.get("MI355_NO_COLSUM_FUSION") != "1"
+
+
 def _ceil8(n):
     return (n + 7) // 8 * 8
 
@@ -117,11 +121,12 @@ class HipGroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(channels))
         self.grad_dst = None        # (dgamma, dbeta) views of the flat gradient buffer in direct-gradient mode
 
-    def forward(self, x, silu, passthrough=False):
-        """passthrough: returns (y, x') where x' is x for the branch that bypasses the norm (see GroupNormFn)."""
+    def forward(self, x, silu, passthrough=False, colsum=False):
+        """passthrough: returns (y, x') where x' is x for the branch that bypasses the norm (see GroupNormFn).
+        colsum: x comes from a convolution with a per-sample bias, whose gradient the backward kernel then also produces."""
         if passthrough and not (torch.is_grad_enabled() and x.requires_grad):
             return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst), x
-        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst, passthrough)
+        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst, passthrough, colsum)
 
 
 class HipLayerNorm(nn.Module):
@@ -167,7 +172,7 @@ class ResnetBlock(nn.Module):
         h, x = self.norm1(x, silu=True, passthrough=True)      # x: the shortcut branch's view of the input
         rb = self._tproj if self._tproj is not None else self.time_emb_proj(temb_act, out_fp32=True)
         h = self.conv1(h, rowbias=rb)
-        h = self.norm2(h, silu=True)
+        h = self.norm2(h, silu=True, colsum=_COLSUM_FUSION and rb.requires_grad)
         res = x if self.conv_shortcut is None else self.conv_shortcut(x)
         return self.conv2(h, residual=res)
 
@@ -178,7 +183,7 @@ class ResnetBlock(nn.Module):
         h = ops.groupnorm_cat(x1, x2, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, True)
         rb = self._tproj if self._tproj is not None else self.time_emb_proj(temb_act, out_fp32=True)
         h = self.conv1(h, rowbias=rb)
-        h = self.norm2(h, silu=True)
+        h = self.norm2(h, silu=True, colsum=_COLSUM_FUSION and rb.requires_grad)
         B, H, W, C1 = x1.shape
         C2 = x2.shape[-1]
         w = sc.pack.w16.view(sc.pack.cout, C1 + C2)
@@ -196,7 +201,7 @@ class ResnetBlock(nn.Module):
                                          sc.bias, sc.weight)
         rb = self._tproj if self._tproj is not None else self.time_emb_proj(temb_act, out_fp32=True)
         h = self.conv1(h, rowbias=rb)
-        h = self.norm2(h, silu=True)
+        h = self.norm2(h, silu=True, colsum=_COLSUM_FUSION and rb.requires_grad)
         return self.conv2(h, residual=res)
 
     def cat_train_ready(self, x1, x2):

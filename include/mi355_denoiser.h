@@ -193,6 +193,13 @@ int mi355_groupnorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int mi355_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
                         const void* dres, void* stream);
+/* mi355_groupnorm_bwd that also returns dx_colsum [B][C] fp32 = per-sample column sums of the dx it stores: when x is the
+ * output of a convolution with a per-sample bias (the timestep-embedding projection added by the first convolution of
+ * a residual block), that is the bias's gradient, and the separate pass over dx is not needed.  colsum_scratch: a
+ * second buffer of mi355_groupnorm_scratch_floats(B, HW, C, G) floats. */
+int mi355_groupnorm_bwd_colsum(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                               void* dx, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C, int G, int silu,
+                               const void* dres, float* dx_colsum, float* colsum_scratch, void* stream);
 /* GroupNorm(+SiLU) forward on the channel concatenation [x1 | x2] of two NHWC tensors (x1 [B][HW][C1], x2 [B][HW][C2])
  * without materialising it: the input of the up-path residual blocks, hidden state | skip connection (the
  * `torch.cat([hidden_states, res_hidden_states], dim=1)` of the third-party up block the reference calls at

@@ -928,3 +928,84 @@ def test_feed_forward_block_as_one_node():
     assert rel_l2(a1, a0.float()) < 5e-3
     for u, v in zip(g1, g0):
         assert rel_l2(u, v.float()) < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 320), (3, 16, 16, 640), (2, 8, 8, 1280), (2, 4, 4, 1280), (2, 8, 8, 2560)])
+def test_groupnorm_backward_with_per_sample_column_sums(shape):
+    """mi355_groupnorm_bwd_colsum against mi355_groupnorm_bwd plus the separate column-sum pass over its result
+    (mi355_colsum_bf16 with one segment per sample): dx, dgamma, dbeta bit-equal, the sums equal up to fp32 summation
+    order - strip kernels and small-map kernel, with and without a bypass gradient."""
+    from image_generator_amd.ops import lib, check, _stream, colsum
+    d = dev()
+    B, H, W, C = shape
+    G, HW = 32, H * W
+    g = torch.Generator().manual_seed(sum(shape) + 3)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3).to(BF).to(d)
+    dy = torch.randn(B, H, W, C, generator=g).to(BF).to(d)
+    res = torch.randn(B, H, W, C, generator=g).to(BF).to(d)
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1).to(d)
+    beta = (torch.randn(C, generator=g) * 0.1).to(d)
+    nsc = int(lib.mi355_groupnorm_scratch_floats(B, HW, C, G))
+    y = torch.empty_like(x)
+    stats = torch.empty(B, G, 2, device=d)
+    sc, sc2 = torch.empty(nsc, device=d), torch.empty(nsc, device=d)
+    check(lib.mi355_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), sc.data_ptr(),
+                                  B, HW, C, G, 1e-5, 1, _stream()))
+    for with_res in (False, True):
+        rp = res.data_ptr() if with_res else None
+        dx0, dg0, db0 = torch.empty_like(x), torch.empty(C, device=d), torch.empty(C, device=d)
+        check(lib.mi355_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                      dx0.data_ptr(), dg0.data_ptr(), db0.data_ptr(), sc.data_ptr(), B, HW, C, G, 1, rp, _stream()))
+        want = colsum(dx0.view(-1, C), seg=HW)
+        dx1, dg1, db1 = torch.empty_like(x), torch.empty(C, device=d), torch.empty(C, device=d)
+        sums = torch.full((B, C), 7.0, device=d)
+        check(lib.mi355_groupnorm_bwd_colsum(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             dx1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), sc.data_ptr(), B, HW, C, G, 1, rp,
+                                             sums.data_ptr(), sc2.data_ptr(), _stream()))
+        assert torch.equal(dx1, dx0) and torch.equal(dg1, dg0) and torch.equal(db1, db0)
+        close(sums, want, 1e-5, 1e-4 * float(want.abs().max()) + 1e-5, "per-sample column sums of dx")
+        close(sums, dx0.float().view(B, HW, C).sum(1), 1e-5, 1e-4 * float(want.abs().max()) + 1e-5, "sums vs torch")
+
+
+def test_resnet_time_embedding_gradient_from_the_norm_backward():
+    """ResnetBlock backward with the first convolution's per-sample bias gradient taken from the second normalisation's
+    backward kernel (ops._DX_COLSUMS) against the separate column-sum pass: gradients of the timestep embedding, of its
+    projection and of the block input - a 16x16 map (strip kernels) and an 8x8 map of 1280 channels (small-map kernel)."""
+    import image_generator_amd.unet as U
+    from image_generator_amd import ops
+    d = dev()
+    for (cin, cout, hw) in ((640, 640, 16), (1280, 1280, 8)):
+        torch.manual_seed(cin + hw)
+        blk = U.ResnetBlock(cin, cout, 1280, 32, 1e-5).to(d)
+        for m in blk.modules():
+            if isinstance(m, (U.HipConv2d, U.HipLinear)):
+                pk = m.pack
+                if isinstance(m, U.HipConv2d):
+                    t = pk.ksize * pk.ksize
+                    pk.w16 = m.weight.data.permute(0, 2, 3, 1).reshape(pk.cout, t, pk.cin).to(BF).contiguous()
+                    pk.w16_t = m.weight.data.flip(2, 3).permute(1, 2, 3, 0).reshape(pk.cin, t, pk.cout).to(BF).contiguous()
+                else:
+                    pk.w16 = m.weight.data.to(BF).contiguous()
+                    pk.w16_t = pk.w16.t().contiguous()
+        x = rnd(2, hw, hw, cin, seed=71).to(d)
+        temb = rnd(2, 1280, seed=72).to(d)
+        dout = rnd(2, hw, hw, cout, seed=73).to(d)
+
+        def run(fused):
+            old = U._COLSUM_FUSION
+            U._COLSUM_FUSION = fused
+            try:
+                for p in blk.parameters():
+                    p.grad = None
+                a, t = x.clone().requires_grad_(True), temb.clone().requires_grad_(True)
+                blk(a, t).backward(dout)
+                torch.cuda.synchronize()
+                assert not ops._DX_COLSUMS          # consumed by the convolution's backward
+                return a.grad, t.grad, blk.time_emb_proj.weight.grad.clone(), blk.time_emb_proj.bias.grad.clone()
+            finally:
+                U._COLSUM_FUSION = old
+
+        ref, got = run(False), run(True)
+        assert torch.equal(got[0], ref[0])
+        for u, v in zip(got[1:], ref[1:]):
+            assert rel_l2(u.float(), v.float()) < 2e-3
