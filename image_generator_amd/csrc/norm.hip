@@ -20,6 +20,25 @@ __device__ __forceinline__ float silu_grad_f(float z) {
     return s * (1.f + z * (1.f - s));
 }
 
+// Group index of each of the 8 consecutive channels c0 .. c0 + 7: one integer division instead of eight (a group of at
+// least 8 channels is crossed at most once inside the chunk).
+__device__ __forceinline__ void gn_groups8(int c0, int cg, int (&gi)[8]) {
+    const int g0 = c0 / cg, rem = c0 - g0 * cg;
+    if (cg >= 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gi[e] = g0 + (rem + e >= cg ? 1 : 0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gi[e] = (c0 + e) / cg;
+    }
+}
+// The 8 consecutive fp32 parameters of a chunk as two 16-byte loads.
+__device__ __forceinline__ void gn_load8(const float* __restrict__ p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+
 // MODE 0: acc0 += x, acc1 += x^2.   MODE 1: dz = dy * act'(z); acc0 += dz, acc1 += dz * xhat.
 // grid = (strips, B); blockDim.x = nc * rows_par (nc = C/8).
 // gpart [B][strips][G][2]: per-group sums of this strip (MODE 1: weighted by gamma).
@@ -41,13 +60,17 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __
     const int cg = C / G;
     float sc[8], sh[8], mu[8], rs[8];
     if (MODE == 1) {
+        int gi[8];
+        gn_groups8(c8 * 8, cg, gi);
+        gn_load8(gamma + c8 * 8, sc);
+        gn_load8(beta + c8 * 8, sh);
+        if (cg >= 8) {                       // at most two groups in the chunk: two pairs of statistics
+            const f32x2 sa = *(const f32x2*)(stats + ((size_t)b * G + gi[0]) * 2), sb = *(const f32x2*)(stats + ((size_t)b * G + gi[7]) * 2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c8 * 8 + e, g = c / cg;
-            mu[e] = stats[((size_t)b * G + g) * 2];
-            rs[e] = stats[((size_t)b * G + g) * 2 + 1];
-            sc[e] = gamma[c];
-            sh[e] = beta[c];
+            for (int e = 0; e < 8; ++e) { mu[e] = gi[e] == gi[0] ? sa[0] : sb[0]; rs[e] = gi[e] == gi[0] ? sa[1] : sb[1]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mu[e] = stats[((size_t)b * G + gi[e]) * 2]; rs[e] = stats[((size_t)b * G + gi[e]) * 2 + 1]; }
         }
     }
     float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -131,7 +154,15 @@ __device__ __forceinline__ void gn_group_sums(const float* __restrict__ gpart, f
     for (int i = threadIdx.x; i < G * 2; i += blockDim.x) {
         const float* src = gpart + (size_t)b * strips * G * 2 + i;
         float s = 0.f;
-        for (int t = 0; t < strips; ++t) s += src[(size_t)t * G * 2];
+        // 16 independent loads per round trip: left as a plain loop the compiler waits for every load before the next
+        // (one L2 round trip per strip, ~10 us of prologue in every block of a 32-strip map)
+        for (int t0 = 0; t0 < strips; t0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = t0 + u < strips ? src[(size_t)(t0 + u) * G * 2] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
         gs[i] = s;
     }
     __syncthreads();
@@ -149,15 +180,22 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
     const float inv_n = 1.f / ((float)HW * cg);
     float sc[8], sh[8];
     const int c8 = threadIdx.x % nc, rp = threadIdx.x / nc, rpar = blockDim.x / nc;
+    {
+        int gi[8];
+        float ga[8], be[8];
+        gn_groups8(c8 * 8, cg, gi);
+        gn_load8(gamma + c8 * 8, ga);
+        gn_load8(beta + c8 * 8, be);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = c8 * 8 + e, g = c / cg;
-        const float mean = gs[g * 2] * inv_n;
-        float var = gs[g * 2 + 1] * inv_n - mean * mean;
-        if (var < 0.f) var = 0.f;
-        const float rstd = rsqrtf(var + eps);
-        sc[e] = rstd * gamma[c];
-        sh[e] = beta[c] - mean * sc[e];
+        for (int e = 0; e < 8; ++e) {
+            const int g = gi[e];
+            const float mean = gs[g * 2] * inv_n;
+            float var = gs[g * 2 + 1] * inv_n - mean * mean;
+            if (var < 0.f) var = 0.f;
+            const float rstd = rsqrtf(var + eps);
+            sc[e] = rstd * ga[e];
+            sh[e] = be[e] - mean * sc[e];
+        }
     }
     if (blockIdx.x == 0) {                   // one block per sample publishes the statistics for the backward pass
         for (int g = threadIdx.x; g < G; g += blockDim.x) {
@@ -221,15 +259,21 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* 
     const int cg = C / G;
     const float inv_n = 1.f / ((float)HW * cg);
     float mu[8], rs[8], ga[8], be[8], m1[8], m2[8];
+    {
+        int gi[8];
+        gn_groups8(c8 * 8, cg, gi);
+        gn_load8(gamma + c8 * 8, ga);
+        gn_load8(beta + c8 * 8, be);
+        if (cg >= 8) {                       // at most two groups in the chunk: two pairs of statistics
+            const f32x2 sa = *(const f32x2*)(stats + ((size_t)b * G + gi[0]) * 2), sb = *(const f32x2*)(stats + ((size_t)b * G + gi[7]) * 2);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = c8 * 8 + e, g = c / cg;
-        mu[e] = stats[((size_t)b * G + g) * 2];
-        rs[e] = stats[((size_t)b * G + g) * 2 + 1];
-        ga[e] = gamma[c];
-        be[e] = beta[c];
-        m1[e] = gs[g * 2] * inv_n;
-        m2[e] = gs[g * 2 + 1] * inv_n;
+            for (int e = 0; e < 8; ++e) { mu[e] = gi[e] == gi[0] ? sa[0] : sb[0]; rs[e] = gi[e] == gi[0] ? sa[1] : sb[1]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mu[e] = stats[((size_t)b * G + gi[e]) * 2]; rs[e] = stats[((size_t)b * G + gi[e]) * 2 + 1]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m1[e] = gs[gi[e] * 2] * inv_n; m2[e] = gs[gi[e] * 2 + 1] * inv_n; }
     }
     const size_t base = (size_t)b * HW * C + c8 * 8;
     // this thread's chunk of every row of x / dres / dx: p + (b * HW + r) * ldx.  Two-source input (see gn_partial_kernel):
