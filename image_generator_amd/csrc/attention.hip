@@ -46,25 +46,12 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return bf16x8{a[0],
 // 16-lane group touches must sit 64 B apart modulo the 256 B bank row.
 __host__ __device__ constexpr int tr_ld(int no) { return (no * 64) % 128 == 64 ? no * 64 : no * 64 + 64; }
 
-// Cooperative copy of `nrows` x `ncols8` 16-byte chunks into LDS (rows >= rows_valid and columns >= D are zero
-// filled), split in two so the global loads of the NEXT tile are in flight while the current tile is
-// being multiplied: tile_load() fills NCH registers per thread (chunk idx = threadIdx.x + 256*i), tile_store()
-// writes them to LDS after the barrier that retires the current tile.
+// Cooperative copy of `nrows` x `ncols8` 16-byte chunks into LDS (rows past the tensor and columns >= D are zero
+// filled), split in two so the global loads of the NEXT tile are in flight while the current tile is being multiplied:
+// TileFetch::load() fills NCH registers per thread (chunk idx = threadIdx.x + 256*i), tile_store() writes them to LDS
+// after the barrier that retires the current tile.
 // ONES: column D of every row (the first padding column) holds 1.0 instead of 0 - a product with this tile then
 // carries the row sums of the other operand in that column for free.
-template <int NCH, bool ONES = false>
-__device__ __forceinline__ void tile_load(bf16x8 (&reg)[NCH], const bf16_t* __restrict__ src, int ld, int rows_valid, int D,
-                                          int nrows, int ncols8) {
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bf16x8 one8 = {(bf16_t)1.0f, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int idx = threadIdx.x + 256 * i;
-        const int r = idx / ncols8, c = idx - r * ncols8;
-        reg[i] = (idx < nrows * ncols8 && r < rows_valid && c * 8 < D) ? *(const bf16x8*)(src + (size_t)r * ld + c * 8)
-                                                                        : ((ONES && c * 8 == D) ? one8 : zero8);
-    }
-}
 // SWZ: 16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3).  Tiles whose row stride is tr_ld() (64 or 192 B
 // modulo the 256-B bank row, what the transposing reads need) put a column of 16 consecutive rows on only four 16-B bank
 // slots, a 4-way conflict for the row-wise ds_read_b128 of a 16-lane group; with the swizzle the 16 rows cover all 16
@@ -85,6 +72,47 @@ __device__ __forceinline__ void tr_cols_swz(int lane, int& c0, int& c1) {
     c0 = (chunk ^ hh) * 16 + b;
     c1 = (chunk ^ (hh + 2)) * 16 + b;
 }
+
+// The fetch goes through a buffer descriptor: a thread's chunks are the same (row, column) slots of every tile, so their
+// byte offsets are computed once; a tile is then NCH loads at (per-thread offset, per-tile scalar offset) with no vector
+// arithmetic, and the rows past the tensor come back as zeros from the descriptor's bounds check (the forward loop is
+// bound by vector issue: per-tile address and bounds arithmetic was 20 of its 157 vector instructions per key tile).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NCH>
+struct TileFetch {
+    __amdgpu_buffer_rsrc_t rs;
+    int voff[NCH];
+    unsigned one[NCH];      // 0x3F80 (bf16 1.0 in the low half of the first dword) for the ones chunk, else 0
+    int row_bytes;
+    template <bool ONES>
+    __device__ __forceinline__ void init(const bf16_t* base, int ld, int rows_valid, int D, int nrows, int ncols8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned bytes = rows_valid > 0 ? (unsigned)(((size_t)(rows_valid - 1) * ld + D) * 2) : 0u;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+#endif
+        row_bytes = ld * 2;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = idx / ncols8, c = idx - r * ncols8;
+            const bool in = idx < nrows * ncols8;
+            voff[i] = (in && c * 8 < D) ? (r * ld + c * 8) * 2 : (int)0x80000000;
+            one[i] = (ONES && in && c * 8 == D) ? 0x3F80u : 0u;
+        }
+    }
+    template <bool ONES>
+    __device__ __forceinline__ void load(bf16x8 (&reg)[NCH], int row0) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int soff = row0 * row_bytes;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0);
+            if (ONES) v[0] |= one[i];
+            reg[i] = __builtin_bit_cast(bf16x8, v);
+        }
+#endif
+    }
+};
 
 // =============================================================================================
 // forward
@@ -139,8 +167,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const int nkt = (Nk + 63) / 64;
     constexpr int NCK = (64 * (DP / 8) + 255) / 256, NCV = (64 * NO * 4 + 255) / 256;
     bf16x8 kreg[NCK], vreg[NCV];
-    tile_load(kreg, Kb, p.ldk, Nk, p.D, 64, DP / 8);
-    tile_load<NCV, ONES>(vreg, Vb, p.ldv, Nk, p.D, 64, NO * 4);
+    TileFetch<NCK> kfetch;
+    TileFetch<NCV> vfetch;
+    kfetch.template init<false>(Kb, p.ldk, Nk, p.D, 64, DP / 8);
+    vfetch.template init<ONES>(Vb, p.ldv, Nk, p.D, 64, NO * 4);
+    kfetch.template load<false>(kreg, 0);
+    vfetch.template load<ONES>(vreg, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
@@ -148,8 +180,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         tile_store(vreg, Vs, VLD, 64, NO * 4);
         __syncthreads();
         if (kt + 1 < nkt) {                       // next tile's loads fly under this tile's MFMAs and softmax
-            tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, Nk - k0 - 64, p.D, 64, DP / 8);
-            tile_load<NCV, ONES>(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, Nk - k0 - 64, p.D, 64, NO * 4);
+            kfetch.template load<false>(kreg, k0 + 64);
+            vfetch.template load<ONES>(vreg, k0 + 64);
         }
 
         // All K fragments of the tile are requested before the first product and the two 32-key blocks alternate, so no
@@ -362,8 +394,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
             else if (threadIdx.x < QT) lreg = INFINITY;     // padded query rows: p = exp2(-inf) = 0
         }
     };
-    tile_load(qreg, Qb, p.ldq, p.Nq, p.D, QT, NO * 4);
-    tile_load(greg, Gb, p.ldo, p.Nq, p.D, QT, NO * 4);
+    TileFetch<NCQ> qfetch, gfetch;
+    qfetch.template init<false>(Qb, p.ldq, p.Nq, p.D, QT, NO * 4);
+    gfetch.template init<false>(Gb, p.ldo, p.Nq, p.D, QT, NO * 4);
+    qfetch.template load<false>(qreg, 0);
+    gfetch.template load<false>(greg, 0);
     load_stats(0);
     for (int qt = 0; qt < nqt; ++qt) {
         const int q0 = qt * QT;
@@ -373,8 +408,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
         if (threadIdx.x < 2 * QT) Ls[threadIdx.x] = lreg;
         __syncthreads();
         if (qt + 1 < nqt) {
-            tile_load(qreg, Qb + (size_t)(q0 + QT) * p.ldq, p.ldq, p.Nq - q0 - QT, p.D, QT, NO * 4);
-            tile_load(greg, Gb + (size_t)(q0 + QT) * p.ldo, p.ldo, p.Nq - q0 - QT, p.D, QT, NO * 4);
+            qfetch.template load<false>(qreg, q0 + QT);
+            gfetch.template load<false>(greg, q0 + QT);
             load_stats(q0 + QT);
         }
 #pragma unroll
@@ -517,8 +552,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
     const int nkt = (Nk + 63) / 64;
     constexpr int NCK = (64 * NO * 4 + 255) / 256, NCV = (64 * (DP / 8) + 255) / 256;
     bf16x8 kreg[NCK], vreg[NCV];
-    tile_load(kreg, Kb, p.ldk, Nk, p.D, 64, NO * 4);
-    tile_load(vreg, Vb, p.ldv, Nk, p.D, 64, DP / 8);
+    TileFetch<NCK> kfetch;
+    TileFetch<NCV> vfetch;
+    kfetch.template init<false>(Kb, p.ldk, Nk, p.D, 64, NO * 4);
+    vfetch.template init<false>(Vb, p.ldv, Nk, p.D, 64, DP / 8);
+    kfetch.template load<false>(kreg, 0);
+    vfetch.template load<false>(vreg, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
@@ -526,8 +565,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnArgs p) {
         tile_store(vreg, Vs, VLD, 64, DP / 8);
         __syncthreads();
         if (kt + 1 < nkt) {
-            tile_load(kreg, Kb + (size_t)(k0 + 64) * p.ldk, p.ldk, Nk - k0 - 64, p.D, 64, NO * 4);
-            tile_load(vreg, Vb + (size_t)(k0 + 64) * p.ldv, p.ldv, Nk - k0 - 64, p.D, 64, DP / 8);
+            kfetch.template load<false>(kreg, k0 + 64);
+            vfetch.template load<false>(vreg, k0 + 64);
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
