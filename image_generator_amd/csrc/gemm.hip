@@ -71,6 +71,11 @@ struct GemmArgs {
     // pre-activation gb_pre [M][2F] = (h | g) the forward pass kept
     const bf16_t* gb_pre;
     bf16_t* gb_out;
+    // k-major B (LDS-DMA kernel, BN = 160 only): Bw holds B[k][n] with n contiguous - a weight [K][N] used untransposed
+    // by the data-gradient product dx = dy W.  bt_ld: elements between consecutive k.  For a convolution the product runs
+    // over (tap, channel) of the stored weight [C][taps][N] (C = g.C output channels of the layer, N its input
+    // channels) with the taps in reverse order: k = tap * C + c reads row c, tap taps-1-tap.
+    int bt, bt_ld;
 };
 
 // AMODE_DENSE_LORA: dense A with the low-rank term in the epilogue - a kernel variant of its own so that every other
@@ -501,6 +506,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr int OOB_OFF = (int)0x80000000;
 
+// Transposing LDS read as inline asm: an LDS read the compiler knows about, other than a plain load, is made to wait for
+// EVERY outstanding `buffer_load ... lds` (vmcnt(0)) - the prefetch of the next tiles would never overlap the products.
+// lds_tr_wait() before the first use of the results.
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_tr_asm(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_tr_wait(bf16x4 (&lo)[N], bf16x4 (&hi)[N]) {
+    static_assert(N == 5 || N == 1, "one register list per fragment count");
+    if constexpr (N == 5)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4])
+                     :: "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]) :: "memory");
+}
+
 // NW = 4: 2x2 waves of 64 x BN/2, two workgroups per CU.  NW = 8: 4x2 waves of 32 x BN/2 on the same tile, for
 // grids of at most one workgroup per CU: a lone 4-wave workgroup has one wave per SIMD, whose DMA issue, LDS
 // reads and MFMAs serialise; eight waves give every SIMD a second wave to overlap them with.
@@ -510,7 +535,12 @@ constexpr int OOB_OFF = (int)0x80000000;
 // NST: LDS stages.  3 (grids of at most one workgroup per CU, which have the LDS to spare): tile kt + 2 is requested
 // while tile kt is multiplied, so a request has two iterations to land instead of one - with one workgroup per CU the
 // 2-stage loop waits on every tile's round trip (~1 600 cycles per k-tile against 640 of MFMA).
-template <int BN, int AMODE, int NW = 4, int BM = 128, int NST = 2>
+// BT: B is k-major (GemmArgs::bt).  A k-tile of B is then 64 rows of BN contiguous values, kept in LDS as [k][BN] (row
+// = 320 B for BN = 160: consecutive rows 64 B apart modulo the 256-B bank row) and read with ds_read_b64_tr_b16, two
+// per fragment: the 16 lanes of a group fetch 4 rows x 16 columns and each receives one column.  The two groups that
+// share an LDS pass read rows 8 apart - the same banks - so the rows of every odd 8-row block are rotated by 32 B
+// (on the source side of the DMA, like the XOR swizzle of the row-major tiles).
+template <int BN, int AMODE, int NW = 4, int BM = 128, int NST = 2, bool BT = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(const GemmArgs p, unsigned a_bytes, unsigned b_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the body uses device-only buffer-resource builtins
     constexpr int BK = 64;
@@ -567,6 +597,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
         }
     }
     int b_voff[B_P];
+    if constexpr (BT) {
+        static_assert(!BT || BN % 16 == 0, "rows of whole 32-byte blocks");
+        constexpr int RCH = BN / 8;             // 16-byte chunks per k row
+#pragma unroll
+        for (int j = 0; j < B_P; ++j) {
+            const int slot = ((wave + NW * j) * 64 + lane) % (64 * RCH);      // (pieces past the tile are never issued)
+            const int k = slot / RCH;
+            int c = slot - k * RCH - 2 * ((k >> 3) & 1);
+            if (c < 0) c += RCH;
+            const int n = n0 + c * 8;
+            b_voff[j] = n < p.N ? (k * p.bt_ld + n) * 2 : OOB_OFF;
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < B_P; ++j) {
         int n = n0 + (wave + NW * j) * 8 + sr;
@@ -609,6 +652,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     auto issue = [&](int kt, int stage) {
         char* As = smem + stage * STAGE;
         char* Bs = As + BM * 128;
+        int soffb = kt * (BK * 2);
+        if constexpr (BT) {
+            if constexpr (amode_dense(AMODE)) soffb = kt * BK * p.bt_ld * 2;
+            else soffb = (cur_c * p.bt_ld + (p.g.ksize == 3 ? 8 - (cur_ky * 3 + cur_kx) : 0) * p.N) * 2;
+        }
         if constexpr (AMODE == AMODE_DENSE_CAT) {
             if (kt * BK < p.K1) {            // (uniform) the k-tile lies in the first source ...
                 const int soff = kt * (BK * 2);
@@ -655,7 +703,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
                 if (++cur_kx == 3) { cur_kx = 0; ++cur_ky; }
             }
         }
-        const int soffb = kt * (BK * 2);
 #pragma unroll
         for (int j = 0; j < B_P; ++j)
             if (B_PIECES % NW == 0 || j < nbp)
@@ -669,6 +716,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
+    // BT: byte offset of this lane's transposing reads inside a k-step's 32 rows, per 16-column block of the wave
+    int bt_off[BT ? TN : 1];
+    if constexpr (BT) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int col = (wn0 + j * 16 + 4 * (fr & 3)) * 2 + 32 * (fq & 1);
+            if (col >= BN * 2) col -= BN * 2;
+            bt_off[j] = (fq * 8 + (fr >> 2)) * (BN * 2) + col;
+        }
+    }
     // NST stages: tiles kt + 1 .. kt + NST - 2 stay in flight while tile kt is multiplied
 #pragma unroll
     for (int d = 0; d < NST - 1; ++d)
@@ -687,6 +744,41 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
         if (kt + NST - 1 < kt_end) issue(kt + NST - 1, cur == 0 ? NST - 1 : cur - 1);
         const char* As = smem + cur * STAGE;
         const char* Bs = As + BM * 128;
+        if constexpr (BT) {
+            // both k-steps' fragments are requested up front, the second step's while the first step multiplies
+            static_assert(!BT || TN == 5, "k-major B: 160-column tiles");
+            bf16x8 af[2][TM];
+            bf16x4 lo[2][BT ? TN : 1], hi[2][BT ? TN : 1];
+            const unsigned bs = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Bs;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ch = ks * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wm0 + i * 16 + fr;
+                    af[ks][i] = *(const bf16x8*)(As + r * 128 + ((ch ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned b0 = bs + bt_off[BT ? j : 0];
+                    if (ks == 0) { lo[0][BT ? j : 0] = lds_tr_asm<0>(b0); hi[0][BT ? j : 0] = lds_tr_asm<4 * BN * 2>(b0); }
+                    else { lo[1][BT ? j : 0] = lds_tr_asm<32 * BN * 2>(b0); hi[1][BT ? j : 0] = lds_tr_asm<36 * BN * 2>(b0); }
+                }
+                if (ks == 0) lds_tr_wait(lo[0], hi[0]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1) lds_tr_wait(lo[1], hi[1]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x4 l = lo[ks][BT ? j : 0], h = hi[ks][BT ? j : 0];
+                    const bf16x8 bf = bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bf, acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[TM], bfr[TN];
@@ -706,6 +798,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
         }
         cur = cur == NST - 1 ? 0 : cur + 1;
     }
@@ -1272,12 +1365,12 @@ static int launch_gemm_pp(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes,
 // Split-K choice by a small cost model (all in microseconds): the grid runs in waves of `capacity`
 // co-resident workgroups (2 per CU); a workgroup spends ~t_tile per 64-deep k-tile; splitting adds the
 // slab write + reduce pass.  Picks the split with the smallest estimated makespan.
-template <int BN, int AMODE>
+template <int BN, int AMODE, bool BT = false>
 static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
     constexpr int smem = 2 * (128 + BN) * 128;
     static std::once_flag attr_set;
     std::call_once(attr_set, [] {
-        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 4, 128, 2, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     });
     const int grid = a.tiles_m * a.tiles_n * a.splitk;
     // measured on the denoiser step: 8 waves win up to two workgroups per CU, 4 waves beyond
@@ -1289,20 +1382,20 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
         constexpr int smem3 = 3 * (128 + BN) * 128;
         static std::once_flag attr83_set;
         std::call_once(attr83_set, [] {
-            (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+            (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8, 128, 3, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
         });
-        hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8, 128, 3>), dim3(grid), dim3(512), smem3, s, a, a_bytes, b_bytes);
+        hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8, 128, 3, BT>), dim3(grid), dim3(512), smem3, s, a, a_bytes, b_bytes);
         return mi355_check_launch("gemm_dma_kernel<8 waves, 3 stages>");
     }
     if (grid <= nw8_max) {
         static std::once_flag attr8_set;
         std::call_once(attr8_set, [] {
-            (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8, 128, 2, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         });
-        hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8>), dim3(grid), dim3(512), smem, s, a, a_bytes, b_bytes);
+        hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 8, 128, 2, BT>), dim3(grid), dim3(512), smem, s, a, a_bytes, b_bytes);
         return mi355_check_launch("gemm_dma_kernel<8 waves>");
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE>), dim3(grid), dim3(256), smem, s, a, a_bytes, b_bytes);
+    hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 4, 128, 2, BT>), dim3(grid), dim3(256), smem, s, a, a_bytes, b_bytes);
     return mi355_check_launch("gemm_dma_kernel");
 }
 
@@ -1363,10 +1456,29 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     static const bool force_v1 = getenv("MI355_GEMM_V1") != nullptr;
     const double a_sz = amode_dense(amode) ? ((double)(a.M - 1) * a.lda + a.K) * 2.0
                                              : (double)a.g.B * a.g.H * a.g.W * a.g.C * 2.0;
-    const double b_sz = ((double)(a.N - 1) * a.ldb + a.K) * 2.0;
+    const double b_sz = a.bt ? (amode_dense(amode) ? ((double)(a.K - 1) * a.bt_ld + a.N) * 2.0 : (double)a.K * a.N * 2.0)
+                             : ((double)(a.N - 1) * a.ldb + a.K) * 2.0;
     const bool dma_ok = !force_v1 && a.K % 64 == 0 && amode != AMODE_CONV_GENERIC && a_sz < 2.0e9 && b_sz < 2.0e9 &&
                         (double)a.M * (amode_dense(amode) ? a.lda : 1) < 1.0e9;
     if (a.geglu && !dma_ok) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_geglu: needs K %% 64 == 0 and operands < 2 GB");
+    if (a.bt) {         // k-major B: the 128 x 160 LDS-DMA kernel only
+        if (!dma_ok || bn != 160 || (amode != AMODE_DENSE && amode != AMODE_CONV_FAST) || a.geglu || (a.bt_ld & 7) ||
+            (amode == AMODE_CONV_FAST && (a.g.C % 64 || a.g.ups)))
+            return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm (k-major B): needs N %% 160 == 0, K (conv: channels) %% 64 == 0, operands < 2 GB");
+        a.bm = 128;
+        const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
+        rc = amode == AMODE_DENSE ? launch_gemm_dma<160, AMODE_DENSE, true>(a, ab, bb, s)
+                                  : launch_gemm_dma<160, AMODE_CONV_FAST, true>(a, ab, bb, s);
+        if (rc) return rc;
+        if (sk > 1) {
+            const size_t total = (size_t)a.M * (a.N / 8);
+            int grid = (int)((total + 255) / 256);
+            if (grid > 2048) grid = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, a);
+            rc = mi355_check_launch("splitk_reduce_kernel");
+        }
+        return rc;
+    }
     a.bm = 128;
     {   // 256-row tiles when the grid still gives every CU its two workgroups
         static const int bm256 = getenv("MI355_GEMM_BM256") ? atoi(getenv("MI355_GEMM_BM256")) : 1;
@@ -1495,6 +1607,46 @@ int mi355_gemm_geglu_bwd_bf16(const void* A, int lda, const void* Bw, int ldb, i
     a.gb_pre = (const bf16_t*)pre; a.gb_out = (bf16_t*)dpre;
     a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
     return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Data gradient of a linear layer from the weight as stored: out [M][N] = A [M][K] W [K][N] (row stride ldw), i.e. the
+// product with the transpose of what mi355_gemm_bf16 takes, without a transposed copy of W.  Optional, as in the
+// entries above: out2 / N1 (columns n >= N1 go to out2 [M][N - N1]), pre / dpre (GEGLU backward in the epilogue: out is
+// then not written).  N must be a multiple of 160, K of 64.
+int mi355_gemm_bt_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, void* out, int ldo,
+                       void* out2, int N1, const void* pre, void* dpre, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !W || (!out && !dpre)) return mi355_fail(MI355_ERR_ARG, "gemm_bt: null pointer");
+    if (out2 && (N1 < 160 || N1 % 160 || N1 >= N)) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_bt: N1 = %d must be a multiple of 160 below N", N1);
+    if ((pre != nullptr) != (dpre != nullptr)) return mi355_fail(MI355_ERR_ARG, "gemm_bt: pre and dpre go together");
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = K;
+    a.bt = 1; a.bt_ld = ldw;
+    a.out = out ? out : dpre; a.ldo = out2 ? N1 : (out ? ldo : N); a.out2 = out2; a.N1 = out2 ? N1 : 0; a.alpha = 1.f;
+    a.gb_pre = (const bf16_t*)pre; a.gb_out = (bf16_t*)dpre;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
+    return run_gemm(a, AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Data gradient of a 3x3 / 1x1 convolution (padding ksize / 2) from the weight as stored, w [Cout][k][k][Cin]:
+// dx [B][Ho][Wo][Cin] = the stride-1 convolution of dy [B][H][W][Cout] (dil: read through a zero-dilation by 2, the
+// gradient of a stride-2 layer) with the transposed, tap-reversed weight - which is never built.  Cin must be a
+// multiple of 160, Cout of 64.
+int mi355_conv2d_dgrad_bt_bf16(const void* dy, int B, int H, int W, int Cout, const void* w, int Cin, int ksize, int dil,
+                               int Ho, int Wo, void* dx, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !w || !dx) return mi355_fail(MI355_ERR_ARG, "conv2d_dgrad_bt: null pointer");
+    if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "conv2d_dgrad_bt: ksize %d (1 or 3 supported)", ksize);
+    if (Cout % 64 || Cin % 160) return mi355_fail(MI355_ERR_UNSUPPORTED, "conv2d_dgrad_bt: Cout = %d must be a multiple of 64, Cin = %d of 160", Cout, Cin);
+    const int Hv = dil ? 2 * H : H, Wv = dil ? 2 * W : W;
+    if (!dil ? (Ho != H || Wo != W) : (Ho > Hv || Wo > Wv || Ho < Hv - 1 || Wo < Wv - 1))
+        return mi355_fail(MI355_ERR_ARG, "conv2d_dgrad_bt: output size %dx%d inconsistent with input %dx%d", Ho, Wo, H, W);
+    const int T = ksize * ksize;
+    GemmArgs a = {};
+    a.A = (const bf16_t*)dy; a.Bw = (const bf16_t*)w;
+    a.M = B * Ho * Wo; a.N = Cin; a.K = T * Cout; a.lda = Cout; a.ldb = a.K;
+    a.bt = 1; a.bt_ld = T * Cin;
+    a.out = dx; a.ldo = Cin; a.rowbias_div = Ho * Wo; a.ldr = Cin; a.alpha = 1.f;
+    a.g = ConvGeom{B, H, W, Cout, Ho, Wo, 1, 0, dil, ksize, ksize / 2};
+    return run_gemm(a, AMODE_CONV_FAST, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,

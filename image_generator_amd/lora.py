@@ -20,7 +20,7 @@ from .ops import BF16, F32, _ptr, _stream, gemm, gemm_skinny
 def _operands(original):
     """(w16 [N][K], w16_t [K][N]) bf16 copies of the base weight, cached until the weight changes."""
     pack = getattr(original, "pack", None)
-    if pack is not None and pack.w16 is not None:
+    if pack is not None and pack.w16 is not None and pack.w16_t is not None:
         return pack.w16, pack.w16_t
     w = original.weight
     key = (w.data_ptr(), w._version, w.device)

@@ -120,6 +120,41 @@ def gemm_geglu_bwd(dout, w_t, pre):
     return dpre
 
 
+def gemm_bt(a, w, n1=0, pre=None):
+    """a[M, K] @ w[K, N] with w read as stored (the data gradient of a linear layer from its [out, in] weight).
+    n1 > 0: returns the column blocks (bf16 [M, n1], bf16 [M, N - n1]) as two tensors.  pre (bf16 [M, 2N]): returns the
+    GEGLU backward [M, 2N] of the product instead of the product (see gemm_geglu_bwd)."""
+    M, K = a.shape
+    N = w.shape[1]
+    assert a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.stride(1) == 1 and w.shape[0] == K
+    ws = workspace(a.device)
+    out = out2 = dpre = None
+    if pre is not None:
+        assert pre.dtype == BF16 and pre.shape == (M, 2 * N) and pre.is_contiguous() and not n1
+        dpre = torch.empty_like(pre)
+    elif n1:
+        out = torch.empty((M, n1), dtype=BF16, device=a.device)
+        out2 = torch.empty((M, N - n1), dtype=BF16, device=a.device)
+    else:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    check(lib.mi355_gemm_bt_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K, _ptr(out), N, _ptr(out2), n1,
+                                 _ptr(pre), _ptr(dpre), ws.data_ptr(), ws.numel(), _stream()), "gemm_bt")
+    return dpre if pre is not None else ((out, out2) if n1 else out)
+
+
+def conv2d_dgrad_bt(dy, w, cin, ksize, dil=False, out_hw=None):
+    """Data gradient [B, Ho, Wo, cin] of a 3x3 / 1x1 convolution from dy [B, H, W, Cout] and the weight as stored,
+    w [Cout][k][k][cin] (dil: the layer had stride 2; out_hw its input size)."""
+    B, H, W, Co = dy.shape
+    Ho, Wo = out_hw if out_hw is not None else (H, W)
+    assert dy.dtype == BF16 and w.dtype == BF16 and dy.is_contiguous() and w.is_contiguous()
+    dx = torch.empty((B, Ho, Wo, cin), dtype=BF16, device=dy.device)
+    ws = workspace(dy.device)
+    check(lib.mi355_conv2d_dgrad_bt_bf16(dy.data_ptr(), B, H, W, Co, w.data_ptr(), cin, ksize, int(dil), Ho, Wo, dx.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_bt")
+    return dx
+
+
 def gemm_skinny(a, w, alpha=1.0):
     """bf16 [M, W] = alpha * a[M, K] @ w[W, K]^T for W in (8, 16): one launch, no split-K workspace."""
     M, K = a.shape
@@ -498,12 +533,14 @@ class WeightPack:
 
     w16   : [N][K] bf16 (forward operand)
     w16_t : data-gradient operand: [K][N] for linear layers, [Cin][k][k][Cout] tap-flipped for convs.
+    bt    : the data gradient reads w16 as stored (gemm_bt / conv2d_dgrad_bt); w16_t is then None and never rebuilt.
     """
     __slots__ = ("w16", "w16_t", "n", "k", "ksize", "cin", "cout", "cin_pad", "cout_pad", "bias_pad", "grad_out",
-                 "bias_grad_out", "on_grad_ready", "bias_parts")
+                 "bias_grad_out", "on_grad_ready", "bias_parts", "bt")
 
     def __init__(self):
         self.bias_parts = 0       # number of trailing bias parameters in LinearFn's `weights` (fused projections)
+        self.bt = False
         self.w16 = self.w16_t = None
         self.bias_pad = None      # fp32 bias padded to cout_pad (convolutions whose Cout is not a multiple of 8)
         self.grad_out = None      # optional fp32 [N][K] view the weight gradient is written into directly
@@ -549,7 +586,10 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy2.contiguous()
         dx = db = dres = None
         if needs[0]:
-            dx = gemm(dy2, pack.w16_t.view(pack.k, pack.n)).view(ctx.xshape)
+            if pack.bt:
+                dx = gemm_bt(dy2, pack.w16.view(pack.n, pack.k)).view(ctx.xshape)
+            else:
+                dx = gemm(dy2, pack.w16_t.view(pack.k, pack.n)).view(ctx.xshape)
         want_db = ctx.has_bias and (needs[2] or any(ctx.breq))
         if ctx.has_res and needs[3]:
             dres = dy2.view(dy.shape)
@@ -642,7 +682,10 @@ class FeedForwardFn(torch.autograd.Function):
         n = ctx.needs_input_grad            # x, residual, pk1, b1, w1, pk2, b2, w2
         pk2 = ctx.c2.pack
         d2 = (dout if dout.dtype == BF16 else dout.to(BF16)).reshape(-1, pk2.n).contiguous()
-        dpre = gemm_geglu_bwd(d2, pk2.w16_t.view(pk2.k, pk2.n), pre)
+        if pk2.bt:
+            dpre = gemm_bt(d2, pk2.w16.view(pk2.n, pk2.k), pre=pre)
+        else:
+            dpre = gemm_geglu_bwd(d2, pk2.w16_t.view(pk2.k, pk2.n), pre)
         _, _, db2, dres, _, dw2 = LinearFn._backward(ctx.c2, y, d2.view(dout.shape), (False, False, n[6], n[1], False, n[7]))
         dx, _, db1, _, _, dw1 = LinearFn._backward(ctx.c1, x2, dpre, (n[0], False, n[3], False, False, n[4]))
         return dx, dres, None, db1, dw1, None, db2, dw2
@@ -696,7 +739,10 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = drb = dres = None
         if ctx.needs_input_grad[0]:
             hv, wv = (2 * H, 2 * W) if ups else (H, W)
-            dxv = conv2d(dy, pack.w16_t, pack.cin_pad, pack.ksize, stride=1, dil=(stride == 2), out_hw=(hv, wv))
+            if pack.bt:
+                dxv = conv2d_dgrad_bt(dy, pack.w16, pack.cin_pad, pack.ksize, dil=(stride == 2), out_hw=(hv, wv))
+            else:
+                dxv = conv2d(dy, pack.w16_t, pack.cin_pad, pack.ksize, stride=1, dil=(stride == 2), out_hw=(hv, wv))
             if ups:
                 dx = torch.empty_like(x)
                 check(lib.mi355_sumpool2x2_bf16(dxv.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "sumpool2x2")
@@ -795,11 +841,14 @@ class CatNormShortcutFn(torch.autograd.Function):
         dr2 = (dres if dres.dtype == BF16 else dres.to(BF16)).contiguous().view(-1, pack.n)
         needs = ctx.needs_input_grad
         # shortcut data gradients, one per source; the normalisation kernel adds them to its own
-        wt = pack.w16_t.view(C, pack.n)
-        if C1 % 320 == 0:
-            d1, d2 = gemm_split(dr2, wt, C1)
+        if pack.bt:
+            d1, d2 = gemm_bt(dr2, pack.w16.view(pack.n, C), n1=C1)
         else:
-            d1, d2 = gemm(dr2, wt[:C1]), gemm(dr2, wt[C1:])
+            wt = pack.w16_t.view(C, pack.n)
+            if C1 % 320 == 0:
+                d1, d2 = gemm_split(dr2, wt, C1)
+            else:
+                d1, d2 = gemm(dr2, wt[:C1]), gemm(dr2, wt[C1:])
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         direct = ctx.gdst is not None
         frozen = not (needs[2] or needs[3])

@@ -64,8 +64,21 @@ class DenoiserConfig:
 _COLSUM_FUSION = os.environ.get("MI355_NO_COLSUM_FUSION") != "1"
 
 
+# data gradients read the weights as stored instead of per-step transposed copies
+_BT_DGRAD = os.environ.get("MI355_NO_BT_DGRAD") != "1"
+
+
 def _ceil8(n):
     return (n + 7) // 8 * 8
+
+
+def _bt_ok(n_in, n_out, weights):
+    """Whether a layer's data gradient reads its weight as stored (ops.gemm_bt / conv2d_dgrad_bt): the layer's inputs in
+    whole 160-column tiles, its outputs in whole 64-deep k-tiles.  Trainable weights only - a frozen layer's transposed
+    copy is built once, and the product on it is ~5 % faster.  Not the 320-channel layers: their large maps run on tile
+    shapes that have no such operand mode, and their weights are the small ones."""
+    return (_BT_DGRAD and n_in % 160 == 0 and n_out % 64 == 0 and min(n_in, n_out) >= 640
+            and all(w.requires_grad for w in weights))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -315,7 +328,7 @@ class FeedForward(nn.Module):
     def forward(self, x, residual):
         g, o = self.net[0].proj, self.net[2]
         if (torch.is_grad_enabled() and isinstance(g, HipLinear) and isinstance(o, HipLinear) and g.pack.w16 is not None
-                and o.pack.w16 is not None and o.pack.w16_t is not None and g.pack.k % 64 == 0 and (g.pack.n // 2) % 80 == 0
+                and o.pack.w16 is not None and (o.pack.w16_t is not None or o.pack.bt) and g.pack.k % 64 == 0 and (g.pack.n // 2) % 80 == 0
                 and os.environ.get("MI355_NO_FF_FUSION") != "1"):
             # training: one autograd node, the gate's backward rides the output projection's data-gradient GEMM
             return FeedForwardFn.apply(x, residual, g.pack, g.bias, g.weight, o.pack, o.bias, o.weight)
@@ -555,11 +568,13 @@ class UNet2DConditionModel(nn.Module):
         self._zero_table = None
         # operand packs
         self._packs = []
+        lora_wrapped = {id(m.original) for m in self.modules() if isinstance(m, LoRALinear)}
         for m in self.modules():
             if isinstance(m, HipLinear):
                 pk, o = m.pack, offs[id(m.weight)]
                 pk.w16 = self._flat16[o:o + pk.n * pk.k].view(pk.n, pk.k)
-                pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
+                pk.bt = _bt_ok(pk.k, pk.n, [m.weight]) and id(m) not in lora_wrapped
+                pk.w16_t = None if pk.bt else torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
                 self._packs.append(("linear", m, pk, o))
             elif isinstance(m, HipConv2d):
                 pk, o = m.pack, offs[id(m.weight)]
@@ -569,7 +584,8 @@ class UNet2DConditionModel(nn.Module):
                     pk.bias_pad = torch.zeros(pk.cout_pad, dtype=F32, device=dev)
                 else:
                     pk.w16 = self._flat16[o:o + pk.cout * t * pk.cin].view(pk.cout, t, pk.cin)
-                pk.w16_t = torch.empty((pk.cin_pad, t, pk.cout_pad), dtype=BF16, device=dev)
+                pk.bt = not m.padded and _bt_ok(pk.cin, pk.cout, [m.weight])
+                pk.w16_t = None if pk.bt else torch.empty((pk.cin_pad, t, pk.cout_pad), dtype=BF16, device=dev)
                 self._packs.append(("conv", m, pk, o))
         for m in self.modules():
             if isinstance(m, Attention):
@@ -586,7 +602,8 @@ class UNet2DConditionModel(nn.Module):
                     pk.w16 = None
                     continue
                 pk.w16 = self._flat16[o0:o0 + pk.n * pk.k].view(pk.n, pk.k)
-                pk.w16_t = torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
+                pk.bt = _bt_ok(pk.k, pk.n, [w.weight for w in ws]) and not any(id(w) in lora_wrapped for w in ws)
+                pk.w16_t = None if pk.bt else torch.empty((pk.k, pk.n), dtype=BF16, device=dev)
                 self._packs.append(("fused", m, pk, o0))
         from types import SimpleNamespace
         for m, ws in fused_groups:
@@ -616,6 +633,8 @@ class UNet2DConditionModel(nn.Module):
         # one job table for every per-step weight transpose: (src, dst, R, C, T, first tile)
         jobs, first = [], 0
         for kind, m, pk, o in self._packs:
+            if pk.bt:
+                continue
             if kind in ("linear", "fused", "temb"):
                 R, C, T = pk.n, pk.k, 1
             else:
@@ -647,7 +666,8 @@ class UNet2DConditionModel(nn.Module):
                 phys = m.weight.data.permute(0, 2, 3, 1).reshape(pk.cout, t, pk.cin)
                 pk.w16[:pk.cout, :, :pk.cin] = phys.to(BF16)
                 pk.bias_pad[:pk.cout] = m.bias.data
-        check(lib.mi355_transpose_batched(self._tjobs.data_ptr(), self._tjobs.shape[0], self._ttiles, s), "transpose_batched")
+        if self._tjobs.shape[0]:
+            check(lib.mi355_transpose_batched(self._tjobs.data_ptr(), self._tjobs.shape[0], self._ttiles, s), "transpose_batched")
         self._sig = self._signature()
 
     def _maybe_refresh(self):

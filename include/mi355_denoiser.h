@@ -95,6 +95,20 @@ int mi355_gemm_cat_bf16(const void* A1, int K1, const void* A2, int K2, const vo
                         int ldo, const float* bias, void* workspace, size_t workspace_bytes, void* stream);
 int mi355_gemm_split_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N1, int N2, int K, void* out1,
                           void* out2, void* workspace, size_t workspace_bytes, void* stream);
+/* Data gradients from the weights as they are stored (what autograd derives for the linear and convolution layers of the
+ * denoiser the reference trains, trainer.py:233-262): no transposed copy of a weight is kept or rebuilt after an
+ * optimizer step.
+ *   mi355_gemm_bt_bf16:          out [M][N] = A [M][K] W, W [K][N] with row stride ldw (the [out][in] weight of a linear
+ *                                layer, A its output gradient).  Optional: out2 / N1 - columns n >= N1 go to out2
+ *                                [M][N - N1] (N1 a multiple of 160); pre / dpre - the GEGLU backward of
+ *                                mi355_gemm_geglu_bwd_bf16 in the epilogue (out may then be null).  N % 160 == 0, K % 64 == 0.
+ *   mi355_conv2d_dgrad_bt_bf16:  dx [B][Ho][Wo][Cin] from dy [B][H][W][Cout] and w [Cout][k][k][Cin] of a 3x3 / 1x1
+ *                                layer with padding k / 2; dil = 1 for a stride-2 layer (dy read through a zero-dilation
+ *                                by 2, Ho in {2H - 1, 2H}).  Cin % 160 == 0, Cout % 64 == 0. */
+int mi355_gemm_bt_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, void* out, int ldo,
+                       void* out2, int N1, const void* pre, void* dpre, void* workspace, size_t workspace_bytes, void* stream);
+int mi355_conv2d_dgrad_bt_bf16(const void* dy, int B, int H, int W, int Cout, const void* w, int Cin, int ksize, int dil,
+                               int Ho, int Wo, void* dx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* 3x3 stride-2 convolution with one pixel of zero padding on the bottom and right only (the AutoencoderKL
  * down-sampler reached through image_generator.py:107-108 `self.vae.encode`): x [B][H][W][C] -> out [B][H/2][W/2][Cout]. */

@@ -1009,3 +1009,94 @@ def test_resnet_time_embedding_gradient_from_the_norm_backward():
         assert torch.equal(got[0], ref[0])
         for u, v in zip(got[1:], ref[1:]):
             assert rel_l2(u.float(), v.float()) < 2e-3
+
+
+@pytest.mark.parametrize("M,Nout,Kin", [(300, 128, 160), (2048, 1280, 1280), (8192, 1920, 640), (32, 1280, 1280), (512, 64, 320)])
+def test_linear_data_gradient_from_the_weight_as_stored(M, Nout, Kin):
+    """mi355_gemm_bt_bf16: dx = dy W with W [out][in] read in place (k-major operand, transposing LDS reads) against fp32
+    math, and bit for bit against the same product on a transposed copy of W (same k order, same accumulators)."""
+    from image_generator_amd import ops
+    d = dev()
+    dy = rnd(M, Nout, seed=81).to(d)
+    w = rnd(Nout, Kin, scale=Nout ** -0.5, seed=82).to(d)
+    got = ops.gemm_bt(dy, w)
+    ref = dy.float() @ w.float()
+    close(got, ref, 2 ** -7, 2e-2, f"gemm_bt {M}x{Kin}x{Nout}")
+    assert rel_l2(got, ref) < 4e-3
+    assert torch.equal(got, ops.gemm(dy, w.t().contiguous()))
+
+
+def test_linear_data_gradient_as_stored_split_and_gated():
+    """The two epilogue options of mi355_gemm_bt_bf16 against the entries that take a transposed copy: the column-split
+    output (shortcut of an up-path residual block) and the GEGLU backward (feed-forward output projection)."""
+    from image_generator_amd import ops
+    d = dev()
+    M, Nout, C1, C2 = 512, 1280, 1280, 640
+    dy = rnd(M, Nout, seed=83).to(d)
+    w = rnd(Nout, C1 + C2, scale=Nout ** -0.5, seed=84).to(d)
+    d1, d2 = ops.gemm_bt(dy, w, n1=C1)
+    e1, e2 = ops.gemm_split(dy, w.t().contiguous(), C1)
+    assert d1.shape == (M, C1) and d2.shape == (M, C2) and torch.equal(d1, e1) and torch.equal(d2, e2)
+    ref = dy.float() @ w.float()
+    assert rel_l2(torch.cat([d1, d2], 1), ref) < 4e-3
+    M, C, Fh = 1024, 640, 2560
+    dout = rnd(M, C, seed=85).to(d)
+    w2 = rnd(C, Fh, scale=C ** -0.5, seed=86).to(d)             # the projection's weight [out = C][in = F]
+    pre = rnd(M, 2 * Fh, seed=87).to(d)
+    got = ops.gemm_bt(dout, w2, pre=pre)
+    assert torch.equal(got, ops.gemm_geglu_bwd(dout, w2.t().contiguous(), pre))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 128, 160, 3, False, None), (2, 8, 8, 1280, 640, 3, False, None),
+                                  (3, 9, 7, 64, 320, 1, False, None), (2, 8, 8, 128, 160, 3, True, (16, 16)),
+                                  (2, 8, 8, 64, 160, 3, True, (15, 15)), (32, 4, 4, 1280, 1280, 3, False, None)])
+def test_conv_data_gradient_from_the_weight_as_stored(case):
+    """mi355_conv2d_dgrad_bt_bf16 (weight [Cout][k][k][Cin] read in place, taps reversed by the addressing) against
+    autograd of an fp32 convolution on the same bf16-rounded operands, and bit for bit against the convolution with the
+    transposed, tap-flipped weight copy.  Stride-2 layers (dil) with even and odd input sizes."""
+    from image_generator_amd import ops
+    d = dev()
+    B, H, W, Co, Ci, k, dil, out_hw = case
+    g = torch.Generator().manual_seed(B * 1000 + Co + Ci + k)
+    dy = torch.randn(B, H, W, Co, generator=g).to(BF).to(d)
+    w = (torch.randn(Co, k, k, Ci, generator=g) * (k * k * Co) ** -0.5).to(BF).to(d)
+    got = ops.conv2d_dgrad_bt(dy, w.view(Co, k * k, Ci), Ci, k, dil=dil, out_hw=out_hw)
+    wt = w.flip(1, 2).permute(3, 1, 2, 0).reshape(Ci, k * k, Co).contiguous()
+    assert torch.equal(got, ops.conv2d(dy, wt, Ci, k, stride=1, dil=dil, out_hw=out_hw))
+    Hi, Wi = out_hw if out_hw is not None else (H, W)
+    x = torch.zeros(B, Ci, Hi, Wi, device=d, requires_grad=True)
+    y = F.conv2d(x, w.float().permute(0, 3, 1, 2), stride=2 if dil else 1, padding=k // 2)
+    assert y.shape == (B, Co, H, W)
+    (ref,) = torch.autograd.grad(y, x, dy.float().permute(0, 3, 1, 2))
+    assert rel_l2(got, ref.permute(0, 2, 3, 1)) < 4e-3
+
+
+def test_model_trains_without_transposed_weight_copies():
+    """The denoiser with data gradients from the weights as stored against the same model on per-step transposed copies
+    (MI355_NO_BT_DGRAD=1 at import: here the module switch): the data gradients are the same products in the same order,
+    so the parameter gradients agree to the fp32 summation order of the pixel-split weight-gradient jobs (atomics);
+    and the eligible packs really hold no transposed copy."""
+    import image_generator_amd.unet as U
+    d = dev()
+    cfg = U.DenoiserConfig(block_out_channels=(640, 1280), layers_per_block=1, down_has_attn=(True, False), num_heads=8,
+                           cross_attention_dim=768, norm_num_groups=32, sample_size=16)
+    x = rnd(2, 4, 16, 16, seed=91).to(d).float()
+    t = torch.tensor([10, 500], device=d)
+    ctx = rnd(2, 77, 768, seed=92).to(d)
+    grads = {}
+    for bt in (True, False):
+        U._BT_DGRAD = bt
+        try:
+            torch.manual_seed(11)
+            net = U.UNet2DConditionModel(cfg).to(d)
+            net.train()
+            out = net(x, t, encoder_hidden_states=ctx).sample
+            out.float().square().mean().backward()
+            nbt = sum(1 for _, _, pk, _ in net._packs if pk.bt)
+            assert (nbt > 10 and all(pk.w16_t is None for _, _, pk, _ in net._packs if pk.bt)) if bt else nbt == 0
+            grads[bt] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        finally:
+            U._BT_DGRAD = True
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 50
+    for n in grads[True]:
+        assert rel_l2(grads[True][n], grads[False][n]) < 1e-5, n
