@@ -1378,6 +1378,13 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
     // at most one workgroup per CU: the LDS for a third stage is free (110 KB of the CU's 160 KB); a fourth (147 KB)
     // measured 0.1 ms/step slower than three
     static const int nst3_max = getenv("MI355_GEMM_NST3") ? atoi(getenv("MI355_GEMM_NST3")) : 256;
+    // k-major B costs two LDS reads per fragment: on long k loops four waves of 64 x 80 (a B fragment feeds four products
+    // instead of two) beat the eight-wave forms (convolutions 1.05-1.07x -> 0.99-1.04x the time of the row-major product);
+    // short loops keep the eight waves, whose second wave per SIMD hides the prologue and epilogue
+    if (BT && a.K >= 2560) {
+        hipLaunchKernelGGL((gemm_dma_kernel<BN, AMODE, 4, 128, 2, BT>), dim3(grid), dim3(256), smem, s, a, a_bytes, b_bytes);
+        return mi355_check_launch("gemm_dma_kernel");
+    }
     if (grid <= nst3_max && grid <= nw8_max) {
         constexpr int smem3 = 3 * (128 + BN) * 128;
         static std::once_flag attr83_set;

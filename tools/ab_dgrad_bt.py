@@ -5,6 +5,9 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from image_generator_amd import ops
+from image_generator_amd._lib import lib
+if len(sys.argv) > 2:
+    lib.mi355_tune_set(int(sys.argv[1]), int(sys.argv[2]))
 
 d = torch.device("cuda:0")
 BF = torch.bfloat16
