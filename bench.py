@@ -220,7 +220,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # multi-GPU (eager) step: the forward pass replayed as a HIP graph from the second warm-up step on, so that the host
+    # enqueues only the backward pass and the optimizer per step; the collectives are never captured
+    fwd_graph = False
     for i in range(args.warmup):
+        if (i == 1 and not graphed and trainer.reducer is not None and not args.no_graph
+                and os.environ.get("MI355_DP_FWD_GRAPH") != "0"):
+            try:
+                trainer.capture_forward(lat, noise, ts, ctx)
+                fwd_graph = True
+            except Exception as e:          # the eager step measures the same arithmetic
+                trainer._fwd_graph = trainer._fwd_loss = None
+                print(f"[bench] forward graph not used: {type(e).__name__}: {e}", file=sys.stderr)
         loss = step(i)
     barrier()
     probe = trainer.opt.flat[:65536].clone()      # to prove afterwards that the timed steps really updated the weights
@@ -256,6 +267,7 @@ def main():
     pair_us = 0.0
     if args.prof_steps > 0:
         trainer._graph = None                      # event timing needs the eager launches
+        trainer._fwd_graph = trainer._fwd_loss = None
         step(args.warmup + args.steps)             # (untimed) first eager step after the graph: allocator warm-up
         torch.cuda.synchronize()
         # An event pair measures its kernels only while the stream is busy: on an idle stream the opening event is
@@ -343,7 +355,7 @@ def main():
                                        "text cross-attention T=77"),
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                           "optimizer": "fused AdamW + global-norm clip", "final_loss": final_loss, "final_grad_norm": gnorm,
-                          "hip_graph": bool(graphed)},
+                          "hip_graph": bool(graphed), "forward_hip_graph": bool(fwd_graph)},
                "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                "rank_ms_per_step": {"max": max(rank_ms), "min": min(rank_ms)},
                "comm_exposed_ms_per_step": comm_exposed,

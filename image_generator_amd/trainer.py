@@ -470,11 +470,21 @@ class DenoiserTrainer:
                               and self.reducer.use_cuda and not self.reducer.unpack and not self.opt.frozen_base
                               and os.environ.get("MI355_NO_DIRECT_STAGE") != "1")
 
-    def forward_backward(self, latents, noise, t, ctx):
+    def _forward_loss(self, latents, noise, t, ctx):
         B = latents.shape[0]
         noisy = torch.empty_like(latents)
         check(lib.mi355_ddpm_add_noise(latents.data_ptr(), noise.data_ptr(), t.data_ptr(), self.acp.data_ptr(),
                                        noisy.data_ptr(), B, latents[0].numel(), _stream()), "ddpm_add_noise")
+        pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
+        return mse_loss(pred, noise)
+
+    def forward_backward(self, latents, noise, t, ctx):
+        if self._fwd_graph is not None:
+            for dst, src in zip(self._static, (latents, noise, t, ctx)):
+                if dst.data_ptr() != src.data_ptr():
+                    # through .data: the recorded tape saved views of these buffers, and a counted in-place write
+                    # would make autograd refuse them - the graph replay rewrites everything else it saved anyway
+                    dst.data.copy_(src, non_blocking=True)
         # with the queue, pixel-split weight gradients are cleared per job and unsplit ones are plain stores
         self.unet.zero_small_grads(weights_too=self.wgrad_queue is None)
         fused = self._fused_sumsq and self.wgrad_queue is not None
@@ -491,11 +501,14 @@ class DenoiserTrainer:
             self.reducer.staged = self.wgrad_queue.covered_map
         self._ops.set_direct_step(True)
         try:
-            pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
-            loss = mse_loss(pred, noise)
+            if self._fwd_graph is not None:
+                self._fwd_graph.replay()                       # refreshes every tensor the recorded tape saved
+                loss = self._fwd_loss
+            else:
+                loss = self._forward_loss(latents, noise, t, ctx)
             self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched
             self._ops.set_reduce_queue(self.reduce_queue)
-            loss.backward()
+            loss.backward(retain_graph=self._fwd_graph is not None)
             if self.wgrad_queue is not None:
                 self.wgrad_queue.join()
                 self._covered = list(self.wgrad_queue.covered) if fused else None
@@ -581,6 +594,7 @@ class DenoiserTrainer:
             self.step_count = ck["step"] + 1
             self.best_loss = ck["loss"]
             self._graph = None                      # a captured step holds the old step counter's hyper-parameters
+            self._fwd_graph = self._fwd_loss = None
             print(f"[INFO] Resumed from {path} | epoch: {ck['epoch']} | step: {self.step_count} | loss: {self.best_loss}")
             return ck["epoch"]
         except Exception as e:                      # the reference reports and carries on (trainer.py:186-189)
@@ -628,6 +642,31 @@ class DenoiserTrainer:
             self._static_loss = self.forward_backward(*self._static)
             opt.apply(covered=self._covered)
         self._graph = g
+
+    # ---- forward-only HIP graph for the data-parallel step
+    _fwd_graph = None
+
+    def capture_forward(self, latents, noise, t, ctx):
+        """The forward pass (add-noise, denoiser, loss) of the eager step as one HIP graph for these shapes.  The backward
+        pass stays eager - its bucket all-reduces are issued from callbacks as gradients complete, and no collective is
+        ever captured - and walks the autograd tape recorded here again every step (`retain_graph`): the tensors the
+        tape saved are the graph's own buffers, which each replay fills with the current step's activations.  Takes the
+        forward's third of the host's enqueue work out of a step whose host and device times are close (one process
+        per GPU has no idle device time to hide a slow host behind).  Call after at least one eager step."""
+        if self._graph is not None:
+            raise RuntimeError("capture_forward(): the whole step is already captured")
+        self.unet._maybe_refresh()                   # (an operand refresh must not end up inside the graph)
+        self._static = tuple(x.clone() for x in (latents, noise, t, ctx))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        self._ops.set_direct_step(True)
+        try:
+            # thread-local capture mode: the process group's watchdog thread may query events meanwhile
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                loss = self._forward_loss(*self._static)
+        finally:
+            self._ops.set_direct_step(False)
+        self._fwd_graph, self._fwd_loss = g, loss
 
     def _replay(self, latents, noise, t, ctx, lr):
         for dst, src in zip(self._static, (latents, noise, t, ctx)):

@@ -71,6 +71,47 @@ def test_dp_step_with_reducer_matches_plain_step(rccl_world1):
     assert la[-1] < la[0]
 
 
+def test_dp_step_with_captured_forward_matches_eager_step(rccl_world1):
+    """DenoiserTrainer.capture_forward: the forward pass replayed as a HIP graph, the backward pass walking the tape
+    recorded at capture (retain_graph) with the reducer's collectives eager.  The kernels and their order are those of
+    the eager step, so losses, gradient norms and weights stay with the eager trainer's over several steps with
+    changing inputs (tolerance: fp32 summation order of atomics only)."""
+    from image_generator_amd.trainer import DenoiserTrainer
+    from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
+    g = torch.Generator().manual_seed(29)
+    batches = [(torch.randn(4, 4, 8, 8, generator=g).to(D), torch.randn(4, 4, 8, 8, generator=g).to(D),
+                torch.randint(0, 1000, (4,), generator=g).to(D), torch.randn(4, 16, 64, generator=g).to(D).to(torch.bfloat16))
+               for _ in range(5)]
+
+    def run(fwd_graph):
+        torch.manual_seed(0)
+        unet = UNet2DConditionModel(DenoiserConfig.small()).to(D)
+        os.environ["MI355_FORCE_REDUCER"] = "1"
+        try:
+            tr = DenoiserTrainer(unet, lr=1e-3, bucket_mb=0.25)
+        finally:
+            os.environ.pop("MI355_FORCE_REDUCER", None)
+        assert tr.reducer is not None and tr.reducer.active
+        losses, norms = [], []
+        for i, b in enumerate(batches):
+            if fwd_graph and i == 1:
+                tr.capture_forward(*b)
+            losses.append(float(tr.train_step(*b)))
+            norms.append(tr.opt.grad_norm())
+        assert (tr._fwd_graph is not None) == fwd_graph
+        return losses, norms, tr.opt.flat.clone()
+
+    try:
+        la, na, wa = run(True)
+    finally:
+        torch.cuda.synchronize()
+    lb, nb, wb = run(False)
+    for a, b in zip(la + na, lb + nb):
+        assert math.isfinite(a) and abs(a - b) <= 1e-5 * abs(b), (la, lb, na, nb)
+    assert float((wa - wb).norm() / wb.norm()) <= 1e-6
+    assert len(set(la)) == len(la)                       # every step saw its own batch
+
+
 def test_lora_dp_step_with_reducer_matches_plain_step(rccl_world1):
     """LoRA fine-tune with the gradient reducer on (one rank over RCCL): the adapters are the reducer's only (tail)
     bucket, the frozen base has none, and the optimizer consumes the staged bf16 adapter gradients - the trajectory

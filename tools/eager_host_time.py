@@ -21,6 +21,11 @@ ts = torch.randint(0, 1000, (B,), device=d)
 for _ in range(3):
     tr.train_step(lat, noise, ts, ctx)
 torch.cuda.synchronize()
+if "--fwd-graph" in sys.argv:          # the forward pass replayed as a HIP graph, backward and optimizer eager
+    tr.capture_forward(lat, noise, ts, ctx)
+    for _ in range(2):
+        tr.train_step(lat, noise, ts, ctx)
+    torch.cuda.synchronize()
 n = 10
 t0 = time.perf_counter()
 for _ in range(n):
@@ -28,7 +33,7 @@ for _ in range(n):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"host enqueue {1e3*(t1-t0)/n:.2f} ms/step, wall {1e3*(t2-t0)/n:.2f} ms/step (reducer: {tr.reducer is not None})")
+print(f"host enqueue {1e3*(t1-t0)/n:.2f} ms/step, wall {1e3*(t2-t0)/n:.2f} ms/step (reducer: {tr.reducer is not None}, forward graph: {tr._fwd_graph is not None})")
 # forward / backward split of the host time
 torch.cuda.synchronize()
 t0 = time.perf_counter()
