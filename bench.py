@@ -223,16 +223,27 @@ def main():
     # multi-GPU (eager) step: the forward pass replayed as a HIP graph from the second warm-up step on, so that the host
     # enqueues only the backward pass and the optimizer per step; the collectives are never captured
     fwd_graph = False
+    want_fwd_graph = (not graphed and trainer.reducer is not None and not args.no_graph
+                      and os.environ.get("MI355_DP_FWD_GRAPH") != "0")
+
+    def capture_forward():
+        try:
+            trainer.capture_forward(lat, noise, ts, ctx)
+            return True
+        except Exception as e:              # the eager step measures the same arithmetic
+            trainer._fwd_graph = trainer._fwd_loss = None
+            print(f"[bench] forward graph not used: {type(e).__name__}: {e}", file=sys.stderr)
+            return False
+
     for i in range(args.warmup):
-        if (i == 1 and not graphed and trainer.reducer is not None and not args.no_graph
-                and os.environ.get("MI355_DP_FWD_GRAPH") != "0"):
-            try:
-                trainer.capture_forward(lat, noise, ts, ctx)
-                fwd_graph = True
-            except Exception as e:          # the eager step measures the same arithmetic
-                trainer._fwd_graph = trainer._fwd_loss = None
-                print(f"[bench] forward graph not used: {type(e).__name__}: {e}", file=sys.stderr)
+        if i == 1 and want_fwd_graph:
+            fwd_graph = capture_forward()
         loss = step(i)
+    if want_fwd_graph and args.warmup < 2:  # fewer than two warm-up steps asked for: capture behind one eager step of
+        if args.warmup == 0:                # our own, and replay once untimed so that no timed step is a first replay
+            step(0)
+        fwd_graph = capture_forward()
+        step(1)
     barrier()
     probe = trainer.opt.flat[:65536].clone()      # to prove afterwards that the timed steps really updated the weights
     if trainer.reducer is not None:
