@@ -13,8 +13,7 @@ for tag in ${TAGS:-base new}; do
   for shape in "${SH[@]}"; do
     n=$(echo $shape | tr ' ' '_')
     timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $O/${tag}_$n -o p -- python3 $R/tools/attn_bench.py $shape > $O/${tag}_$n.log 2>&1
-    f=$(find $O/${tag}_$n -name '*kernel_stats.csv' | head -1)
     echo "== $tag $shape"; tail -1 $O/${tag}_$n.log
-    grep -E "attn_" $f | awk -F, '{printf "   %-60s calls %s avg_ns %s\n", substr($1,1,60), $2, $4}'
+    python3 $R/tools/rocpd_kernels.py $O/${tag}_$n attn_        # per-kernel averages from the run's rocpd database
   done
 done
