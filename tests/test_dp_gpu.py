@@ -71,7 +71,8 @@ def test_dp_step_with_reducer_matches_plain_step(rccl_world1):
     assert la[-1] < la[0]
 
 
-def test_dp_step_with_captured_forward_matches_eager_step(rccl_world1):
+@pytest.mark.parametrize("lora", [False, True])
+def test_dp_step_with_captured_forward_matches_eager_step(rccl_world1, lora):
     """DenoiserTrainer.capture_forward: the forward pass replayed as a HIP graph, the backward pass walking the tape
     recorded at capture (retain_graph) with the reducer's collectives eager.  The kernels and their order are those of
     the eager step, so losses, gradient norms and weights stay with the eager trainer's over several steps with
@@ -85,7 +86,13 @@ def test_dp_step_with_captured_forward_matches_eager_step(rccl_world1):
 
     def run(fwd_graph):
         torch.manual_seed(0)
-        unet = UNet2DConditionModel(DenoiserConfig.small()).to(D)
+        unet = UNet2DConditionModel(DenoiserConfig.small())
+        if lora:                                         # frozen base, rank-4 adapters as the only trainable parameters
+            from image_generator_amd.generator import inject_lora
+            with torch.no_grad():
+                for ad in inject_lora(unet, r=4, alpha=0.5):
+                    ad.lora_B.weight.normal_(0, 0.05)
+        unet.to(D)
         os.environ["MI355_FORCE_REDUCER"] = "1"
         try:
             tr = DenoiserTrainer(unet, lr=1e-3, bucket_mb=0.25)
