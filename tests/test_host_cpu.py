@@ -30,6 +30,9 @@ def test_library_rejects_bad_arguments_without_touching_the_gpu():
         check(lib.mi355_attention_fwd(1, 1, 1, 1, None, 1, 8, 16, 16, 200, 8, 8, 8, 8, 1.0, None), "attention")
     assert lib.mi355_groupnorm_scratch_floats(2, 64, 320, 32) > 0
     assert lib.mi355_colsum_scratch_floats(1024, 320, 1024) > 0
+    # split-K workspace: 16 fp32 slabs of the output, capped at 256 MiB
+    assert lib.mi355_gemm_workspace_bytes(512, 1280) == 16 * 512 * 1280 * 4
+    assert lib.mi355_gemm_workspace_bytes(32768, 10240) == 256 << 20
 
 
 def test_product_fails_loudly_on_cpu_tensors():
@@ -167,6 +170,7 @@ def test_lmdb_reader_and_dataset(tmp_path):
     assert info["depth"] >= 3 and info["overflow"] > n
     env = dp.LMDBEnv(d)
     assert env.entries == 2 * n
+    assert int(env._lib.mi355_lmdb_depth(env._env)) == info["depth"] and int(env._lib.mi355_lmdb_page_size(env._env)) == 4096
     for k, v in items.items():
         assert env.get(k) == v, k
     assert env.get(b"image-99999999") is None and env.get(b"") is None and env.get(b"zzz") is None
