@@ -12,6 +12,7 @@
 // distinct banks.  The pixel range is split across workgroups (split-K); partial sums are combined
 // with fp32 atomics into a zero-initialised (or accumulating) fp32 gradient buffer.
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 
 struct WgradArgs {
@@ -705,6 +706,18 @@ int mi355_wgrad_job_fill_cat(void* host_job, const void* dy, const void* x1, int
     a.x2 = (const bf16_t*)x2; a.C1 = C1;
     a.x_bytes = (unsigned)x1_sz; a.x2_bytes = (unsigned)x2_sz;        // (both below the 2 GB the concatenation was checked against)
     return nb;
+}
+
+// Reorders njobs records in HOST memory so that the jobs whose workgroups walk the most k-tiles come first (ties keep
+// their order) and renumbers their blocks: the launch then drains on its shortest workgroups instead of on whichever
+// layer was queued last.  Returns the total block count (unchanged).
+int mi355_wgrad_jobs_sort(void* host_jobs, int njobs) {
+    if (!host_jobs || njobs <= 0) return mi355_fail(MI355_ERR_ARG, "wgrad_jobs_sort: bad arguments");
+    WgradJob* j = (WgradJob*)host_jobs;
+    std::stable_sort(j, j + njobs, [](const WgradJob& x, const WgradJob& y) { return x.a.kt_per_split > y.a.kt_per_split; });
+    int first = 0;
+    for (int i = 0; i < njobs; ++i) { j[i].first_block = first; first += j[i].nblocks; }
+    return first;
 }
 
 // jobs: DEVICE copy of njobs records; total_blocks = sum of their block counts.

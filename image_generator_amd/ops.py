@@ -284,6 +284,8 @@ class WgradQueue:
         self._refs = []
         self._cbs = []
         self._splits = ctypes.c_int(0)
+        # longest-running jobs first in every launch (MI355_WGRAD_SORT=0: in the order they were queued)
+        self.sort_jobs = os.environ.get("MI355_WGRAD_SORT", "1") != "0"
         # destinations of pixel-split jobs accumulate with atomics: the queue zeroes exactly those (one launch per
         # flush) when `zero_split_outputs` is set, so the owner need not clear the whole gradient buffer every step
         self.zero_split_outputs = False
@@ -362,6 +364,8 @@ class WgradQueue:
 
         def launch():
             nz = len(self._zero)
+            if self.sort_jobs and self._n > 1:
+                check(min(lib.mi355_wgrad_jobs_sort(self._host.data_ptr(), self._n), 0), "wgrad_jobs_sort")
             table = torch.empty(nbytes + 16 * nz, dtype=torch.uint8, device=self.device)
             if nz:
                 zt = self._host[nbytes:nbytes + 16 * nz].view(torch.int64)

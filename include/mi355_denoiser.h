@@ -163,6 +163,10 @@ int mi355_wgrad_job_fill(void* host_job, const void* dy, const void* x, float* d
  * multiple of 160, C2 of 8.  Other arguments and the return value as for mi355_wgrad_job_fill. */
 int mi355_wgrad_job_fill_cat(void* host_job, const void* dy, const void* x1, int C1, const void* x2, int C2, float* dw,
                              float* dbias, int M, int Cout, int first_block, int* splits_out, float* sumsq_slots, void* dw_bf16);
+/* Optional, before the records are copied to the device: puts the jobs whose workgroups run longest (most pixels per
+ * workgroup) first and renumbers first_block, so that the grouped launch ends on its shortest workgroups.  Returns the
+ * total block count.  No counterpart in the reference (its weight gradients are autograd's, trainer.py:247). */
+int mi355_wgrad_jobs_sort(void* host_jobs, int njobs);
 int mi355_wgrad_grouped(const void* jobs, int njobs, int total_blocks, double flops, void* stream);
 
 /* out[s][n] = sum of the rows of segment s (seg rows each) of y[M][N] (bias / broadcast gradients). */

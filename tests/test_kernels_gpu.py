@@ -765,6 +765,54 @@ def test_weight_gradient_job_on_two_sources(case):
                                         None, None, None) < 0
 
 
+def test_weight_gradient_launch_sorted_by_workgroup_length():
+    """mi355_wgrad_jobs_sort puts the jobs with the longest workgroups first and renumbers their blocks: a grouped launch
+    of mixed layers (3x3 and dense, unsplit and pixel-split, short and long pixel ranges) gives the gradients of the
+    launch in queue order bit for bit where a job is unsplit, to accumulation order where it is split, and the records
+    come out ordered."""
+    import ctypes
+    import numpy as np
+    from image_generator_amd.ops import lib, WgradQueue
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    jobs = [(2, 4, 64, 64, 3), (32, 32, 40, 48, 3), (4, 8, 160, 320, 1), (32, 16, 64, 32, 3), (1, 16, 320, 160, 1), (40, 32, 16, 24, 1)]
+    ops_in = []
+    for (B, H, ci, co, k) in jobs:
+        ops_in.append((torch.randn(B, H, H, ci, generator=g).to(BF).to(d), torch.randn(B, H, H, co, generator=g).to(BF).to(d)))
+    outs = {}
+    for sort in (False, True):
+        q = WgradQueue(d, flush_blocks=1 << 30)
+        q.sort_jobs = sort
+        res, splits = [], []
+        for (B, H, ci, co, k), (x, dy) in zip(jobs, ops_in):
+            dw, db = torch.zeros(co, k * k, ci, device=d), torch.zeros(co, device=d)
+            q.push(dy.view(-1, co), x, dw, db, B, H, H, ci, co, k, 1, False, H, H)
+            splits.append(q._splits.value)
+            res.append((dw, db))
+        if sort:        # the records as the launch will see them
+            jb = int(lib.mi355_wgrad_job_bytes())
+            total = lib.mi355_wgrad_jobs_sort(q._host.data_ptr(), q._n)
+            assert total == q._blocks
+            raw = q._host[:q._n * jb].numpy().reshape(q._n, jb)
+            first = raw[:, jb - 8:jb - 4].copy().view(np.int32).ravel()
+            nblk = raw[:, jb - 4:].copy().view(np.int32).ravel()
+            assert first[0] == 0 and (first[1:] == np.cumsum(nblk)[:-1]).all()
+        q.join()
+        torch.cuda.synchronize()
+        outs[sort] = (res, splits)
+    assert outs[False][1] == outs[True][1] and max(outs[True][1]) > 1 and min(outs[True][1]) == 1
+    for (a, da), (b, db), sp, (B, H, ci, co, k), (x, dy) in zip(outs[False][0], outs[True][0], outs[True][1], jobs, ops_in):
+        assert float(a.abs().max()) > 0
+        if sp == 1:
+            assert torch.equal(a, b)
+        else:
+            close(b, a, 1e-4, 1e-4 * float(a.abs().max()), "sorted split wgrad")
+        close(db, da, 1e-4, 1e-3, "sorted wgrad bias gradient")
+        ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (co, ci, k, k), dy.float().permute(0, 3, 1, 2),
+                                          padding=k // 2).permute(0, 2, 3, 1).reshape(co, k * k, ci)
+        close(b, ref, 2e-2, 2e-2 * float(ref.abs().max()), "sorted wgrad vs fp32")
+
+
 def test_up_path_resnet_trains_without_the_concatenation():
     """ResnetBlock.forward_cat_train (ops.CatNormShortcutFn: two-source normalisation forward and backward, split shortcut,
     one two-source weight-gradient job) against the block on torch.cat([hidden, skip]) in the trainer's gradient mode
