@@ -1590,12 +1590,14 @@ int mi355_gemm_cat_bf16(const void* A1, int K1, const void* A2, int K2, const vo
 }
 
 // [out1 | out2] = A Bw^T written as two tensors: out1 [M][N1] takes the first N1 columns, out2 [M][N2] the rest
-// (A [M][K] with row stride lda, Bw [N1 + N2][K] with row stride ldb).  N1 must be a multiple of 320, N2 of 8.
+// (A [M][K] with row stride lda, Bw [N1 + N2][K] with row stride ldb).  N1 must be a multiple of 320 and N1 + N2 of
+// 160: the kernels pick the destination once per tile, so no tile may straddle N1 - with N1 + N2 a multiple of 160 the
+// launcher takes 160- or 320-column tiles, which divide N1; any other width would get 128-column tiles, which do not.
 int mi355_gemm_split_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N1, int N2, int K, void* out1,
                           void* out2, void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !Bw || !out1 || !out2) return mi355_fail(MI355_ERR_ARG, "gemm_split: null pointer");
-    if (N1 < 320 || N1 % 320 || N2 < 8 || (N2 & 7))
-        return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_split: N1 = %d must be a multiple of 320, N2 = %d of 8", N1, N2);
+    if (N1 < 320 || N1 % 320 || N2 < 8 || (N2 & 7) || (N1 + N2) % 160)
+        return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_split: N1 = %d must be a multiple of 320 and N1 + N2 = %d of 160", N1, N1 + N2);
     GemmArgs a = {};
     a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N1 + N2; a.K = K; a.lda = lda; a.ldb = ldb;
     a.out = out1; a.ldo = N1; a.out2 = out2; a.N1 = N1; a.alpha = 1.f;

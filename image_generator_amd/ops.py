@@ -849,7 +849,7 @@ class CatNormShortcutFn(torch.autograd.Function):
             d1, d2 = gemm_bt(dr2, pack.w16.view(pack.n, C), n1=C1)
         else:
             wt = pack.w16_t.view(C, pack.n)
-            if C1 % 320 == 0:
+            if C1 % 320 == 0 and C % 160 == 0:      # (no tile of the product may straddle C1: see mi355_gemm_split_bf16)
                 d1, d2 = gemm_split(dr2, wt, C1)
             else:
                 d1, d2 = gemm(dr2, wt[:C1]), gemm(dr2, wt[C1:])

@@ -18,15 +18,15 @@ and the dropout on the attention probabilities live inside the flash-attention k
 three dropouts of a layer are fused with the residual add / the GELU, and the pooled output is L2-normalised by a row
 kernel.  Dropout masks are hashes of (seed, position): they are regenerated in the backward pass, never stored; the
 seed of a forward pass is drawn from torch's CPU generator, so `torch.manual_seed` makes a run repeatable (the masks are
-not torch's own: the two random streams differ, the statistics do not).  CPU tensors take the PyTorch tensor ops below.
+not torch's own: the two random streams differ, the statistics do not).
+
+There is one backend.  CPU tensors, and geometries the kernels do not carry (width or head width not a multiple of 8,
+heads wider than 96), raise: nothing here computes the encoder with tensor ops instead.
 """
 from __future__ import annotations
 
-import math
-
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 def _kernels():
@@ -175,6 +175,8 @@ class _SelfAttn(nn.Module):
 
 
 class _EncoderLayer(nn.Module):
+    """Parameter container with `nn.TransformerEncoderLayer`'s names; the arithmetic is TextEncoder's."""
+
     def __init__(self, d, h, ff, p):
         super().__init__()
         self.self_attn = _SelfAttn(d, h)
@@ -183,20 +185,6 @@ class _EncoderLayer(nn.Module):
         self.norm1 = nn.LayerNorm(d)
         self.norm2 = nn.LayerNorm(d)
         self.p = p
-
-    def forward(self, x, pad):
-        b, t, d = x.shape
-        h = self.self_attn.num_heads
-        qkv = F.linear(x, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
-        q, k, v = (z.view(b, t, h, d // h).transpose(1, 2) for z in qkv.split(d, dim=-1))
-        s = (q @ k.transpose(-1, -2)) / math.sqrt(d // h)
-        if pad is not None:
-            s = s.masked_fill(pad[:, None, None, :], float("-inf"))
-        a = F.dropout(torch.softmax(s, dim=-1), self.p, self.training) @ v
-        a = self.self_attn.out_proj(a.transpose(1, 2).reshape(b, t, d))
-        x = self.norm1(x + F.dropout(a, self.p, self.training))
-        f = self.linear2(F.dropout(F.gelu(self.linear1(x)), self.p, self.training))
-        return self.norm2(x + F.dropout(f, self.p, self.training))
 
 
 class _Encoder(nn.Module):
@@ -221,7 +209,7 @@ class TextEncoder(nn.Module):
         D = self.embedding.embedding_dim
         H = self.transformer.layers[0].self_attn.num_heads
         x = ops.cast_bf16(self.embedding(input_ids).contiguous()).view(B * T, D)      # gather, then fp32 -> bf16
-        kv_len = self._key_counts(attention_mask)
+        kv_len, bad = self._key_counts(attention_mask)
         for i, layer in enumerate(self.transformer.layers):
             pre = f"transformer.layers.{i}."
             sa = layer.self_attn
@@ -236,25 +224,35 @@ class TextEncoder(nn.Module):
             x = x.view(B, T, D).masked_fill(~attention_mask.bool()[:, :, None], 0.0).view(B * T, D)   # padded rows leave as zeros
         x = ops.layernorm_bf16(x.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps)
         y = ops.gemm(x, w16["projection.weight"], bias=self.projection.bias, out_fp32=True)
-        return y.view(B, T, -1)
+        return self._poison(y.view(B, T, -1), bad)
 
     # The kernels take the key-padding mask as a count of leading valid keys per sample: tokenizers pad on the right
-    # (tokenizer/tokenizer.py:4-9 sets no padding side, the library default is right).  By default that is trusted - checking
-    # it costs a host synchronisation inside every `encode_text` / training step; `check_mask_layout = True` verifies
-    # it and raises instead of computing something else.
+    # (tokenizer/tokenizer.py:4-9 sets no padding side, the library default is right).  The reference honours any mask
+    # (encoder/text_encoder.py:31-34), so a sample whose mask is NOT of that form - left-padded, with holes, or without
+    # a single valid token - must not come back as some other arithmetic's result: the layout is verified on the device
+    # (a few [B, T] tensor ops, no host synchronisation, legal inside a stream capture) and every output row of such a
+    # sample is returned as NaN, which the step's non-finite guards then see.  `check_mask_layout = True` verifies on
+    # the host instead (one synchronisation per call) and raises.
     check_mask_layout = False
 
     def _key_counts(self, attention_mask):
+        """(valid-key counts [B] int32 clamped to >= 1, [B] bool: the mask of this sample is not a right-padded one)."""
         if attention_mask is None:
-            return None
+            return None, None
         m = attention_mask.bool()
         kv_len = m.sum(dim=1).to(torch.int32)
-        if self.check_mask_layout:
-            T = m.shape[1]
-            if not bool((m == (torch.arange(T, device=m.device)[None, :] < kv_len[:, None])).all()) or int(kv_len.min()) < 1:
-                raise ValueError("TextEncoder: attention_mask must be right-padded with at least one valid token per row "
-                                 "(the HIP attention kernels take the mask as valid-key counts)")
-        return kv_len.clamp_(min=1)
+        T = m.shape[1]
+        bad = (m != (torch.arange(T, device=m.device)[None, :] < kv_len[:, None])).any(dim=1) | (kv_len < 1)
+        if self.check_mask_layout and bool(bad.any()):
+            raise ValueError("TextEncoder: attention_mask must be right-padded with at least one valid token per row "
+                             "(the HIP attention kernels take the mask as valid-key counts)")
+        return kv_len.clamp_(min=1), bad
+
+    @staticmethod
+    def _poison(y, bad):
+        if bad is None:
+            return y
+        return y.masked_fill(bad.view(-1, *([1] * (y.dim() - 1))), float("nan"))
 
     def _train_packs(self):
         """Operand packs (bf16 [N][K] and its transpose) of every weight matrix for the training path, rebuilt when a
@@ -295,7 +293,7 @@ class TextEncoder(nn.Module):
         H = self.transformer.layers[0].self_attn.num_heads
         p = float(self.transformer.layers[0].p) if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,))) if p > 0 else 0     # CPU generator: no device synchronisation
-        kv_len = self._key_counts(attention_mask)
+        kv_len, bad = self._key_counts(attention_mask)
         x = _ToBf16Fn.apply(self.embedding(input_ids)).view(B * T, D)
         for i, layer in enumerate(self.transformer.layers):
             pre = f"transformer.layers.{i}."
@@ -321,29 +319,23 @@ class TextEncoder(nn.Module):
             x0 = x.view(B, T, D)[:, 0].contiguous()
             x0 = LayerNormFn.apply(x0, self.norm.weight, self.norm.bias, self.norm.eps)
             y = LinearFn.apply(x0, packs["projection.weight"], self.projection.bias, None, True, self.projection.weight)
-            return _L2NormFn.apply(y)
+            return self._poison(_L2NormFn.apply(y), bad)
         x = LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
         y = LinearFn.apply(x, packs["projection.weight"], self.projection.bias, None, True, self.projection.weight)
-        return y.view(B, T, -1)
+        return self._poison(y.view(B, T, -1), bad)
 
-    def _hip_ok(self, input_ids):
+    def _require_kernels(self, input_ids):
         d = self.embedding.embedding_dim
         h = self.transformer.layers[0].self_attn.num_heads
-        return input_ids.is_cuda and d % 8 == 0 and (d // h) % 8 == 0 and d // h <= 96
+        if not input_ids.is_cuda:
+            raise RuntimeError("TextEncoder: inputs and parameters must live on the HIP device (there is no CPU path)")
+        if d % 8 or d % h or (d // h) % 8 or d // h > 96:
+            raise ValueError(f"TextEncoder: embed_dim {d} with {h} heads is not carried by the kernels (the width and the "
+                             "head width must be multiples of 8, heads at most 96 wide); there is no other backend")
 
     def forward(self, input_ids, attention_mask, return_pooled=True):
-        if self._hip_ok(input_ids):
-            train_path = torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters()))
-            if train_path or return_pooled:
-                return self._forward_train_hip(input_ids, attention_mask, return_pooled)
-            return self._forward_hip(input_ids, attention_mask)
-        x = self.embedding(input_ids)
-        pad = ~attention_mask.bool() if attention_mask is not None else None
-        for layer in self.transformer.layers:
-            x = layer(x, pad)
-        if pad is not None and not (self.training and torch.is_grad_enabled()):
-            x = x.masked_fill(pad[:, :, None], 0.0)     # inference path: padded rows are zero-filled
-        x = self.norm(x)
-        if return_pooled:
-            return F.normalize(self.projection(x[:, 0]), dim=-1)
-        return self.projection(x)
+        self._require_kernels(input_ids)
+        train_path = torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters()))
+        if train_path or return_pooled:
+            return self._forward_train_hip(input_ids, attention_mask, return_pooled)
+        return self._forward_hip(input_ids, attention_mask)

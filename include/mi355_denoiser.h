@@ -85,7 +85,8 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
  *   mi355_gemm_cat_bf16:   out [M][N] = [A1 | A2] Bw^T + bias; A1 [M][K1], A2 [M][K2] contiguous, Bw [N][K1 + K2] (row
  *                          stride ldb); K1, K2 multiples of 64, N of 160.
  *   mi355_gemm_split_bf16: [out1 | out2] = A Bw^T as two tensors, out1 [M][N1], out2 [M][N2]; Bw [N1 + N2][K]; N1 a
- *                          multiple of 320, N2 of 8. */
+ *                          multiple of 320 and N1 + N2 of 160 (a tile goes to one destination: none may straddle N1);
+ *                          other widths return MI355_ERR_UNSUPPORTED. */
 /* Data gradient of the feed-forward output projection with the GEGLU backward in its epilogue: the product
  * dy [M][F] = A Bw^T is not written; dpre [M][2F] = (dy * gelu(g) | dy * h * gelu'(g)) is, from pre [M][2F] = (h | g), the
  * pre-activation mi355_gemm_geglu_bf16 kept.  A [M][K] (row stride lda), Bw [F][K] (row stride ldb); F, K multiples of 8. */

@@ -866,3 +866,59 @@ def test_encoder_dropout_training_mode_and_trainer_step():
         w = dict(enc.named_parameters())[n_]
         assert torch.equal(pk.w16, w.detach().to(torch.bfloat16)) and torch.equal(pk.w16_t, pk.w16.t().contiguous())
     assert tr.crit.log_temp.grad is not None
+    assert tr.skipped_steps() == 0
+
+    # (5) a non-finite image embedding: the step changes nothing - weights, moments, bf16 operand copies and the loss's
+    # temperature stay as they were - and is counted (the GradScaler of train_encoder.py:107-110 skips such a step too)
+    before = {n_: p.detach().clone() for n_, p in enc.named_parameters()}
+    m_before = [m.clone() for m in tr.m]
+    temp_before = tr.crit.log_temp.detach().clone()
+    bad_img = img.clone()
+    bad_img[2, 5] = float("inf")
+    loss, _ = tr.train_step(ids, mask, bad_img)
+    assert not torch.isfinite(loss)
+    for n_, p in enc.named_parameters():
+        assert torch.equal(p.detach(), before[n_]), n_
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(tr.m, m_before))
+    assert torch.equal(tr.crit.log_temp.detach(), temp_before)
+    for n_, pk in enc._train_packs().items():
+        assert torch.equal(pk.w16, before[n_].to(torch.bfloat16))
+    assert tr.skipped_steps() == 1
+    loss, _ = tr.train_step(ids, mask, img)                 # and the next finite step moves again
+    assert torch.isfinite(loss) and tr.skipped_steps() == 1
+    assert not torch.equal(dict(enc.named_parameters())["projection.weight"].detach(), before["projection.weight"])
+    assert not torch.equal(tr.crit.log_temp.detach(), temp_before)
+
+
+def test_text_encoder_refuses_what_the_kernels_do_not_carry_and_marks_masks_it_cannot_honour():
+    """One backend: a geometry outside the kernels' range raises on the device as on the CPU (no tensor-op arithmetic
+    in its place); a sample whose attention mask is not right-padded (the reference honours any mask,
+    encoder/text_encoder.py:31-34; the kernels take valid-key counts) comes back as NaN rows on every path - inference
+    sequence, pooled, training - while the other samples of the batch are what they are without it."""
+    from image_generator_amd.text_encoder import TextEncoder
+    wide = TextEncoder(vocab_size=64, embed_dim=208, num_layers=1, n_head=2, projection_dim=16).to(D)       # heads of 104
+    odd = TextEncoder(vocab_size=64, embed_dim=40, num_layers=1, n_head=2, projection_dim=16).to(D)         # heads of 20
+    ids = torch.randint(4, 64, (2, 6), device=D)
+    mask = torch.ones(2, 6, dtype=torch.long, device=D)
+    for enc in (wide, odd):
+        with torch.no_grad(), pytest.raises(ValueError, match="no other backend"):
+            enc(ids, mask, return_pooled=False)
+    z, enc = _encoder_step_fixture()
+    ids, mask = torch.from_numpy(z["ids"]).to(D), torch.from_numpy(z["mask"]).to(D)
+    holed = mask.clone()
+    holed[2, 1] = 0                                     # sample 2 (9 valid tokens): a hole
+    holed[5] = torch.flip(mask[5], dims=[0])            # sample 5 (7 valid tokens): left-padded
+    enc.eval()
+    with torch.no_grad():
+        good_seq, bad_seq = enc(ids, mask, return_pooled=False), enc(ids, holed, return_pooled=False)
+        good_p, bad_p = enc(ids, mask, return_pooled=True), enc(ids, holed, return_pooled=True)
+    enc.train()
+    for layer in enc.transformer.layers:
+        layer.p = 0.0
+    bad_t = enc(ids, holed, return_pooled=True)
+    marked = [2, 5]
+    rest = [i for i in range(ids.shape[0]) if i not in marked]
+    for good, bad in ((good_seq, bad_seq), (good_p, bad_p), (good_p, bad_t.detach())):
+        assert torch.isnan(bad[marked]).all()
+        assert torch.isfinite(bad[rest]).all()
+    assert torch.equal(bad_seq[rest], good_seq[rest]) and torch.equal(bad_p[rest], good_p[rest])

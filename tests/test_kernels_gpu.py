@@ -911,6 +911,32 @@ def test_gemm_on_two_sources_and_into_two_destinations(case):
                                      ws.data_ptr(), ws.numel(), None) != 0
 
 
+@pytest.mark.parametrize("n2", [160, 480, 64, 192])
+def test_gemm_split_never_lets_a_tile_straddle_the_two_destinations(n2):
+    """N1 = 320 with N1 + N2 a multiple of 160 runs on 160-column tiles (none straddles N1) and equals the plain product
+    bit for bit; any other total width would take 128-column tiles, one of which would cross N1, and is refused."""
+    from image_generator_amd import ops
+    from image_generator_amd.ops import lib
+    d = dev()
+    M, K, N1 = 300, 128, 320
+    g = torch.Generator().manual_seed(n2)
+    a = torch.randn(M, K, generator=g).to(BF).to(d)
+    w = (torch.randn(N1 + n2, K, generator=g) * K ** -0.5).to(BF).to(d)
+    if (N1 + n2) % 160 == 0:
+        full = ops.gemm(a, w)
+        o1, o2 = ops.gemm_split(a, w, N1)
+        assert torch.equal(o1, full[:, :N1]) and torch.equal(o2, full[:, N1:])
+    else:
+        o1 = torch.zeros(M, N1, dtype=BF, device=d)
+        o2 = torch.zeros(M + 1, n2, dtype=BF, device=d)
+        ws = ops.workspace(d)
+        rc = lib.mi355_gemm_split_bf16(a.data_ptr(), K, w.data_ptr(), K, M, N1, n2, K, o1.data_ptr(), o2.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), None)
+        assert rc != 0 and b"160" in lib.mi355_last_error()
+        torch.cuda.synchronize()
+        assert float(o1.float().abs().max()) == 0 and float(o2.float().abs().max()) == 0
+
+
 @pytest.mark.parametrize("case", [(32768, 320, 1280), (8192, 640, 2560), (2048, 1280, 5120), (512, 1280, 5120), (200, 64, 80)])
 def test_geglu_backward_in_the_gemm_epilogue(case):
     """mi355_gemm_geglu_bwd_bf16 (data gradient of the feed-forward output projection with the gate's backward in its
