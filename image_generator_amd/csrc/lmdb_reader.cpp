@@ -109,12 +109,22 @@ void* mi355_lmdb_open(const char* path) {
     if (map == MAP_FAILED) { close(fd); mi355_fail(MI355_ERR_ARG, "lmdb_open: mmap of %s failed", file.c_str()); return nullptr; }
     Env* e = new Env;
     e->map = (const uint8_t*)map; e->size = (size_t)st.st_size; e->fd = fd;
-    // meta page 0 tells the page size, which places meta page 1
+    // meta page 0 tells the page size, which places meta page 1; when page 0 itself does not validate (a torn write:
+    // liblmdb then runs on page 1) page 1 is looked for at the page sizes liblmdb can have used - the common 4096
+    // first, then every power of two from 512 to 64 KiB - and must name the size it was found at
     const Meta m0 = read_meta(e->map);
     Meta best = m0;
-    if (m0.ok && m0.psize >= 512 && (size_t)2 * m0.psize <= e->size) {
+    if (m0.ok && m0.psize >= 512 && !(m0.psize & (m0.psize - 1)) && (size_t)2 * m0.psize <= e->size) {
         const Meta m1 = read_meta(e->map + m0.psize);
-        if (m1.ok && m1.txnid > m0.txnid) best = m1;
+        if (m1.ok && m1.psize == m0.psize && m1.txnid > m0.txnid) best = m1;
+    } else {
+        best = Meta();
+        static const uint32_t sizes[] = {4096, 512, 1024, 2048, 8192, 16384, 32768, 65536};
+        for (const uint32_t ps : sizes) {
+            if ((size_t)2 * ps > e->size) continue;
+            const Meta m1 = read_meta(e->map + ps);
+            if (m1.ok && m1.psize == ps) { best = m1; break; }
+        }
     }
     if (!best.ok || best.psize < 512 || (best.psize & (best.psize - 1))) {
         mi355_fail(MI355_ERR_ARG, "lmdb_open: %s is not an LMDB data file (format version 1)", file.c_str());

@@ -144,6 +144,52 @@ def encoder_step_golden():
     npz("encoder_step.npz", **out)
 
 
+D96 = dict(vocab_size=300, embed_dim=192, num_layers=2, n_head=2, projection_dim=64, dropout=0.2)
+
+
+def text_encoder_d96_golden():
+    """The reference TextEncoder at its own head width (encoder/text_encoder.py:6-27: 768 / 8 = 96) on a narrower
+    model: 192 wide, 2 heads of 96.  Weights are NOT stored: tests/seeded_weights.py regenerates them.  Stored: eval-mode
+    sequence and pooled outputs, train-mode sequence output (dropout disabled), and one contrastive step
+    (encoder/train_encoder.py:103-108) with the loss and the gradient of every parameter."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from seeded_weights import text_encoder_state
+    from encoder.text_encoder import TextEncoder
+    from loss import ContrastiveLoss
+    torch.manual_seed(500)
+    m = TextEncoder(**D96)
+    sd = text_encoder_state(500, D96["vocab_size"], D96["embed_dim"], D96["num_layers"], D96["projection_dim"])
+    assert sorted(sd) == sorted(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    B, T = 8, 12
+    lens = torch.tensor([12, 5, 9, 1, 12, 7, 3, 10])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).long()
+    ids = torch.randint(4, 300, (B, T)) * mask
+    ids[:, 0] = 1
+    out = {"ids": ids, "mask": mask}
+    m.eval()
+    with torch.no_grad():
+        out["eval_seq"] = m(ids, mask, return_pooled=False)
+        out["eval_pooled"] = m(ids, mask, return_pooled=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    for layer in m.transformer.layers:
+        layer.self_attn.dropout = 0.0
+    m.train()
+    out["train_seq"] = m(ids, mask, return_pooled=False).detach()
+    crit = ContrastiveLoss(0.07)
+    img = torch.randn(B, D96["projection_dim"], requires_grad=True)
+    pooled = m(input_ids=ids, attention_mask=mask)
+    loss = crit(pooled, img)
+    loss.backward()
+    out.update({"img": img.detach(), "pooled": pooled.detach(), "loss": loss.detach(), "d_img": img.grad,
+                "d_log_temp": crit.log_temp.grad, "log_temp": crit.log_temp.detach()})
+    for k, v in m.named_parameters():
+        out["grad__" + k] = v.grad
+    npz("text_encoder_d96.npz", **out)
+
+
 def collate_golden():
     from utils.collate_fn import skip_broken_collate_fn
     torch.manual_seed(400)
@@ -213,6 +259,7 @@ if __name__ == "__main__":
     loss_golden()
     text_encoder_golden()
     encoder_step_golden()
+    text_encoder_d96_golden()
     collate_golden()
     try:
         tokenizer_golden()

@@ -922,3 +922,74 @@ def test_text_encoder_refuses_what_the_kernels_do_not_carry_and_marks_masks_it_c
         assert torch.isnan(bad[marked]).all()
         assert torch.isfinite(bad[rest]).all()
     assert torch.equal(bad_seq[rest], good_seq[rest]) and torch.equal(bad_p[rest], good_p[rest])
+
+
+def test_text_encoder_at_the_reference_head_width_96_matches_reference_vectors():
+    """The reference's own geometry is 768 / 8 = heads of 96 (encoder/text_encoder.py:6-27), the widest the masked /
+    dropout attention kernels carry and the variant without a ones column.  tests/golden/text_encoder_d96.npz was minted
+    from the reference modules on a 192-wide encoder with 2 heads of 96 (weights regenerated from
+    tests/seeded_weights.py): inference sequence and pooled outputs, training-mode sequence output, and one contrastive
+    step - loss, image-embedding, temperature and EVERY parameter gradient.  bf16 activations, fp32 accumulation: outputs
+    2e-2 relative L2, loss 5e-3 relative, parameter gradients cosine >= 0.995 and 0.1 relative L2."""
+    import os
+    import numpy as np
+    from seeded_weights import text_encoder_state
+    from image_generator_amd import ops
+    from image_generator_amd.loss import ContrastiveLoss
+    from image_generator_amd.text_encoder import TextEncoder
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "text_encoder_d96.npz"))
+    enc = TextEncoder(vocab_size=300, embed_dim=192, num_layers=2, n_head=2, projection_dim=64, dropout=0.2)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in text_encoder_state(500, 300, 192, 2, 64).items()})
+    enc = enc.to(D).eval()
+    enc.check_mask_layout = True
+    ids, mask = torch.from_numpy(z["ids"]).to(D), torch.from_numpy(z["mask"]).to(D)
+
+    def rel(a, b):
+        return float((a.float().cpu() - b).norm() / b.norm())
+    seen = []
+    orig = ops.attention_fwd
+    ops.attention_fwd = lambda q, *a, **k: (seen.append(q.shape[-1] // a[2]), orig(q, *a, **k))[1]
+    try:
+        with torch.no_grad():
+            seq = enc(ids, mask, return_pooled=False)
+    finally:
+        ops.attention_fwd = orig
+    assert seen == [96, 96]                                   # the masked inference kernel ran, at head width 96
+    assert rel(seq, torch.from_numpy(z["eval_seq"])) <= 2e-2
+    with torch.no_grad():
+        assert rel(enc(ids, mask, return_pooled=True), torch.from_numpy(z["eval_pooled"])) <= 2e-2
+    enc.train()
+    for layer in enc.transformer.layers:
+        layer.p = 0.0                                         # the fixture was minted with dropout disabled
+    with torch.no_grad():
+        t = enc(ids, mask, return_pooled=False).float().cpu()
+    rt, valid = torch.from_numpy(z["train_seq"]), torch.from_numpy(z["mask"]).bool()
+    assert float((t[valid] - rt[valid]).norm() / rt[valid].norm()) <= 2e-2
+    # the contrastive step
+    crit = ContrastiveLoss(0.07).to(D)
+    img = torch.from_numpy(z["img"]).to(D).requires_grad_(True)
+    pooled = enc(ids, mask, return_pooled=True)
+    loss = crit(pooled, img)
+    loss.backward()
+    assert rel(pooled.detach(), torch.from_numpy(z["pooled"])) <= 2e-2
+    assert abs(float(loss) - float(z["loss"])) <= 5e-3 * float(z["loss"]), (float(loss), float(z["loss"]))
+    worst = 1.0
+    for n, p in enc.named_parameters():
+        want, got = torch.from_numpy(z["grad__" + n]), p.grad.float().cpu()
+        if float(want.norm()) < 1e-12:
+            assert float(got.norm()) <= 1e-6, n
+            continue
+        c = float(torch.dot(got.flatten(), want.flatten()) / (got.norm() * want.norm() + 1e-30))
+        worst = min(worst, c)
+        assert c >= 0.995 and float((got - want).norm() / want.norm()) <= 0.1, (n, c)
+    assert rel(img.grad, torch.from_numpy(z["d_img"])) <= 2e-2
+    assert abs(float(crit.log_temp.grad) - float(z["d_log_temp"])) <= 2e-2 * abs(float(z["d_log_temp"]))
+    print(f"head width 96: worst parameter-gradient cosine {worst:.5f}")
+    # with the reference's dropout the same geometry runs the dropout variants of the kernels: repeatable per seed
+    for layer in enc.transformer.layers:
+        layer.p = 0.2
+    def run(seed):
+        torch.manual_seed(seed)
+        return enc(ids, mask, return_pooled=True).detach()
+    a, b, c = run(5), run(5), run(6)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()

@@ -190,6 +190,18 @@ def test_lmdb_reader_and_dataset(tmp_path):
         assert env.get(k) == v, k
     assert env.get(b"image-99999999") is None and env.get(b"") is None and env.get(b"zzz") is None
     env.close()
+    # a torn meta page 0 (here: its magic overwritten): the environment opens on meta page 1, as liblmdb would
+    torn = tmp_path / "torn"
+    torn.mkdir()
+    blob = bytearray((d / "data.mdb").read_bytes())
+    live = 0 if env_live_meta(blob) == 0 else 1
+    if live == 0:                # make page 1 the live one by swapping the two meta pages' bodies (pgno fields aside)
+        blob[16:4096], blob[4096 + 16:8192] = blob[4096 + 16:8192], blob[16:4096]
+    blob[16:20] = b"\0\0\0\0"
+    (torn / "data.mdb").write_bytes(bytes(blob))
+    env = dp.LMDBEnv(torn)
+    assert env.entries == 2 * n and env.get(dp.lmdb_keys(17)[1]) == items[dp.lmdb_keys(17)[1]]
+    env.close()
     with pytest.raises(OSError):
         dp.LMDBEnv(tmp_path / "missing")
     (tmp_path / "junk").write_bytes(b"\0" * 8192)
@@ -226,6 +238,13 @@ def test_lmdb_reader_and_dataset(tmp_path):
             return (print, ("executed",))
     with pytest.raises(Exception, match="only plain"):
         dp.load_metadata(pk.dumps({"raw_text": Evil()}))
+
+
+def env_live_meta(blob):
+    """Index of the meta page with the larger transaction id (page size 4096)."""
+    import struct
+    txn = [struct.unpack_from("<Q", blob, pg * 4096 + 16 + 24 + 48 + 56)[0] for pg in (0, 1)]
+    return 0 if txn[0] > txn[1] else 1
 
 
 def Image_open_rgb(blob):

@@ -61,6 +61,29 @@ def test_text_encoder_oracle_matches_reference_vectors(golden_dir):
     assert float(d[~pad].max()) < 1e-5 and float(d[pad].max()) > 1e-3
 
 
+def test_text_encoder_oracle_matches_reference_vectors_at_head_width_96(golden_dir):
+    """The same restatement against the reference module at its own head width (192 wide, 2 heads of 96; weights
+    regenerated from tests/seeded_weights.py): eval and train sequence outputs, pooled output, and the contrastive step's
+    loss and parameter gradients through autograd of the restatement."""
+    from seeded_weights import text_encoder_state
+    z = np.load(os.path.join(golden_dir, "text_encoder_d96.npz"))
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in text_encoder_state(500, 300, 192, 2, 64).items()}
+    ids, mask = _t(z, "ids"), _t(z, "mask")
+    with torch.no_grad():
+        assert torch.allclose(ops_ref.text_encoder_forward(sd, ids, mask, 2, False, True), _t(z, "eval_seq"), rtol=1e-5, atol=5e-6)
+        assert torch.allclose(ops_ref.text_encoder_forward(sd, ids, mask, 2, True, True), _t(z, "eval_pooled"), rtol=1e-5, atol=5e-6)
+        assert torch.allclose(ops_ref.text_encoder_forward(sd, ids, mask, 2, False, False), _t(z, "train_seq"), rtol=1e-5, atol=5e-6)
+    pooled = ops_ref.text_encoder_forward(sd, ids, mask, 2, True, False)
+    img, lt = _t(z, "img").requires_grad_(True), _t(z, "log_temp").clone().requires_grad_(True)
+    loss = ops_ref.contrastive_loss(pooled, img, lt)
+    loss.backward()
+    assert torch.allclose(loss, _t(z, "loss"), rtol=1e-5)
+    assert torch.allclose(img.grad, _t(z, "d_img"), rtol=1e-3, atol=1e-6)
+    for k, v in sd.items():
+        want = _t(z, "grad__" + k)
+        assert float((v.grad - want).norm()) <= 1e-4 * float(want.norm()) + 1e-7, k
+
+
 def test_collate_oracle(golden_dir):
     z = np.load(os.path.join(golden_dir, "collate.npz"))
     meta = json.load(open(os.path.join(golden_dir, "collate.json")))

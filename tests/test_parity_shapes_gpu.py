@@ -366,10 +366,12 @@ def test_contrastive_loss_at_reference_batch(B, Dm):
     assert abs(float(m.log_temp.grad) - float(lt.grad)) <= 2e-3 * abs(float(lt.grad)) + 1e-6
 
 
-def test_integer_rows_hold_on_the_gpu_box_too(golden_dir):
-    """The bit-exact host rows (tokenizer ids, sampler / LMDB-key indexing, LR schedule, DDIM timesteps) are CPU logic;
-    running them under the gpu marker as well puts them in the same run as the kernels they feed."""
+def test_integer_rows_hold_on_the_gpu_box_too(golden_dir, tmp_path):
+    """The bit-exact host rows (tokenizer ids, sampler / LMDB-key indexing, LR schedule, DDIM timesteps, the LMDB page
+    walker with the dataset on top of it) are CPU logic; running them under the gpu marker as well puts them in the same
+    run as the kernels they feed."""
     import test_host_cpu as h
+    h.test_lmdb_reader_and_dataset(tmp_path)
     h.test_tokenizer_ids_bit_exact(golden_dir)
     h.test_dataplane_indexing_bit_exact(golden_dir)
     h.test_lr_schedule_matches_torch(golden_dir)

@@ -26,11 +26,15 @@ def _run_both(B, HW, C, G, silu, seed):
     check(lib.mi355_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y0.data_ptr(), s0.data_ptr(),
                                   scratch.data_ptr(), B, HW, C, G, 1e-5, int(silu), _stream()), "groupnorm_fwd")
     torch.cuda.synchronize()
+    # torch's counter sees its own caching allocator only; the driver's free-byte figure (hipMemGetInfo) sees a hipMalloc
+    # from anywhere in the process, the library included
     before = torch.cuda.memory_stats(d)["allocation.all.allocated"]
+    free_before = torch.cuda.mem_get_info(d)[0]
     check(lib.mi355_groupnorm_fwd_static(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y1.data_ptr(), s1.data_ptr(),
                                          B, HW, C, G, 1e-5, int(silu), _stream()), "groupnorm_fwd_static")
     torch.cuda.synchronize()
     assert torch.cuda.memory_stats(d)["allocation.all.allocated"] == before
+    assert torch.cuda.mem_get_info(d)[0] == free_before, "device memory was allocated during the call"
     # and against plain fp32 math, so that "equal" cannot mean "equally wrong"
     xf = x.float().cpu().view(B, HW, G, C // G)
     mean, var = xf.mean((1, 3), keepdim=True), xf.var((1, 3), unbiased=False, keepdim=True)
@@ -48,6 +52,38 @@ def test_static_groupnorm_matches_scratch_entry_point_twice():
         assert torch.equal(s0, s1), "statistics differ from mi355_groupnorm_fwd"
         err = (y1.float().cpu() - ref).abs()
         assert float((err / (1.0 + ref.abs())).max()) < 2 ** -6, float(err.max())
+
+
+def test_static_groupnorm_runs_inside_a_stream_capture():
+    """The callers it is for: under a stream capture an allocating HIP call is illegal and fails the capture.  The entry
+    point is captured (after one eager call, which has looked the array's address up), replayed on new input values,
+    and gives the scratch entry point's bits."""
+    from image_generator_amd._lib import lib, check
+    from image_generator_amd.ops import _stream
+    d = torch.device("cuda:0")
+    B, HW, C, G = 2, 1024, 320, 32
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, HW, C, generator=g).to(BF).to(d)
+    gamma, beta = torch.randn(C, generator=g).to(d), torch.randn(C, generator=g).to(d)
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    s0, s1 = torch.empty(B, G, 2, device=d), torch.empty(B, G, 2, device=d)
+    scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, HW, C, G)), device=d)
+
+    def static_call():
+        check(lib.mi355_groupnorm_fwd_static(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y1.data_ptr(), s1.data_ptr(),
+                                             B, HW, C, G, 1e-5, 1, _stream()), "groupnorm_fwd_static")
+    static_call()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_call()
+    x.copy_((torch.randn(B, HW, C, generator=g) * 2 - 0.5).to(BF))
+    y1.zero_()
+    graph.replay()
+    check(lib.mi355_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y0.data_ptr(), s0.data_ptr(),
+                                  scratch.data_ptr(), B, HW, C, G, 1e-5, 1, _stream()), "groupnorm_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16)) and torch.equal(s0, s1)
 
 
 def test_static_groupnorm_rejects_oversize():
