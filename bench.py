@@ -70,14 +70,29 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
-def launch_ranks(n, argv, entry=None, check_devices=True):
-    """Start n ranks of this benchmark (one process per GPU) and return their exit status.  Must run before anything in
-    this process initialises a GPU: counting devices does not."""
-    if check_devices:
-        have = torch.cuda.device_count()
-        if have < n:
-            print(f"[bench] --gpus {n} requested but only {have} GPU(s) are visible; not measuring fewer", file=sys.stderr)
-            return 2
+def visible_gpu_count():
+    """GPUs a rank of this benchmark would see, counted WITHOUT loading a GPU runtime into this process: a throw-away
+    child asks torch (which honours HIP_/ROCR_/CUDA_VISIBLE_DEVICES and whatever devices the container was given - the
+    kfd topology in /sys lists the host's GPUs, not the container's).  None when the child could not tell."""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except (subprocess.SubprocessError, ValueError, IndexError, OSError):
+        return None
+
+
+def launch_ranks(n, argv, entry=None, need_devices=None):
+    """Start n ranks of this benchmark (one process per GPU) and return their exit status.  The launching process does
+    nothing GPU-side, before or after: it counts devices through a child (`visible_gpu_count`), refuses with status 2
+    when there are fewer than `need_devices` (default n: one per rank), and otherwise waits for the ranks."""
+    need = n if need_devices is None else need_devices
+    have = visible_gpu_count()
+    if have is not None and have < need:
+        print(f"[bench] --gpus {n} requested but only {have} GPU(s) are visible; not measuring fewer", file=sys.stderr)
+        return 2
+    if have is None:            # the ranks check for themselves (init_distributed refuses a LOCAL_RANK without a device)
+        print("[bench] could not count the visible GPUs; every rank will check its own device", file=sys.stderr)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -85,6 +100,7 @@ def launch_ranks(n, argv, entry=None, check_devices=True):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC for RCCL between processes
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), entry or os.path.abspath(__file__), *argv]
+    print(f"[bench] {have if have is not None else '?'} GPU(s) visible; starting {n} rank(s): {' '.join(cmd[1:8])} ...", file=sys.stderr)
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -174,7 +190,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))        # nothing has touched a GPU in this process yet
-    from image_generator_amd.trainer import DenoiserTrainer, init_distributed
+    import image_generator_amd.trainer as trainer_mod
+    from image_generator_amd.trainer import DenoiserTrainer
+    init_distributed = trainer_mod.init_distributed       # (looked up late: the one-GPU rehearsal substitutes its own)
     from image_generator_amd.unet import UNet2DConditionModel, DenoiserConfig
     from image_generator_amd._lib import lib
     import torch.distributed as dist
@@ -185,7 +203,11 @@ def main():
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a line for another world size",
               file=sys.stderr)
         sys.exit(2)
-    rank, world, local = init_distributed()
+    try:
+        rank, world, local = init_distributed()
+    except trainer_mod.NoDeviceForRank as e:    # a rank without a GPU of its own never measures on somebody else's
+        print(f"[bench] {e}", file=sys.stderr)
+        sys.exit(2)
     if world > 1 and dist.get_world_size() != args.gpus:
         raise RuntimeError(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     dev = torch.device("cuda", local)
@@ -370,6 +392,7 @@ def main():
                "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                "rank_ms_per_step": {"max": max(rank_ms), "min": min(rank_ms)},
                "comm_exposed_ms_per_step": comm_exposed,
+               "gradient_exchange": trainer.exchange_summary(),
                "step_mfma_frac": step_flops / (ms * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12) if not args.small else None,
                "roofline": roof}
         if world == 1 and not args.no_extra and not args.small and not args.lora:

@@ -454,6 +454,7 @@ class DenoiserTrainer:
         flush = int(os.environ.get("MI355_WGRAD_FLUSH", "4096" if self.reducer is not None else "16384"))
         self.wgrad_queue = (_ops.WgradQueue(dev, flush_blocks=flush, side_stream=side)
                             if os.environ.get("MI355_NO_WGRAD_QUEUE") != "1" else None)
+        self._flush_blocks = flush
         if self.wgrad_queue is not None:
             self.wgrad_queue.zero_split_outputs = True
         # norm-layer parameter gradients: one batched reduction per step instead of one launch per layer
@@ -549,6 +550,20 @@ class DenoiserTrainer:
     def full_grad(self):
         """fp32 copy of the last step's whole gradient (see FusedAdamW.full_grad)."""
         return self.opt.full_grad(self._covered)
+
+    def exchange_summary(self):
+        """What the gradient exchange of a data-parallel step looks like (None on a single process): bucket count and
+        bf16 bytes per all-reduce, the tail bucket of small parameters, the weight-gradient flush size that decides in how
+        many portions the gradients become ready, and which communicator carries the all-reduces."""
+        r = self.reducer
+        if r is None:
+            return None
+        sizes = [2 * (e - s0) for s0, e, _ in r.buckets]
+        return {"buckets": len(sizes), "bucket_bytes_bf16": {"min": min(sizes) if sizes else 0, "max": max(sizes) if sizes else 0,
+                                                             "total": sum(sizes)},
+                "tail_bytes_bf16": 2 * (r.tail[1] - r.tail[0]), "wgrad_flush_blocks": self._flush_blocks,
+                "communicator": "library (mi355_dp_*)" if r.native is not None else "torch process group",
+                "world": r.world}
 
     def train_step(self, latents, noise, t, ctx, epoch_float=None):
         lr = None if epoch_float is None else cosine_warm_restarts_lr(self.base_lr, epoch_float)
@@ -688,11 +703,19 @@ def unet_on_gpu(unet):
     return next(unet.parameters()).device.type == "cuda"
 
 
+class NoDeviceForRank(RuntimeError):
+    pass
+
+
 def init_distributed():
-    """One process per GPU (torchrun env): RCCL process group, returns (rank, world, local_rank)."""
+    """One process per GPU (torchrun env): RCCL process group, returns (rank, world, local_rank).  A LOCAL_RANK without a
+    visible GPU of its own raises `NoDeviceForRank` before any group is created (two ranks never share a device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    have = torch.cuda.device_count()
+    if have and local >= have:
+        raise NoDeviceForRank(f"rank {rank}: LOCAL_RANK {local} but only {have} GPU(s) are visible to this process")
     if (world > 1 or os.environ.get("MI355_FORCE_REDUCER") == "1") and "RANK" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

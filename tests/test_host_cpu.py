@@ -251,3 +251,15 @@ def Image_open_rgb(blob):
     import io
     from PIL import Image
     return Image.open(io.BytesIO(blob)).convert("RGB")
+
+
+def test_bench_refuses_more_ranks_than_visible_gpus_without_touching_a_gpu():
+    """`python bench.py --gpus N` with fewer than N GPUs visible (none in a CPU container) exits 2 with a message and
+    prints no line; the launching process itself never loads a GPU runtime (the count comes from a child)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch as _t
+    n = _t.cuda.device_count() + 1 if _t.cuda.device_count() else 2
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--small"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "GPU(s) are visible" in r.stderr and '"metric"' not in r.stdout

@@ -46,6 +46,7 @@ if __name__ == "__main__":
         rank_main()
     else:
         argv = ["--gpus", "2"] + sys.argv[1:]
-        rc = bench.launch_ranks(2, argv, entry=os.path.abspath(__file__), check_devices=False)
+        # the launcher's own device count runs too; two ranks share the one GPU here, so one device is enough
+        rc = bench.launch_ranks(2, argv, entry=os.path.abspath(__file__), need_devices=1)
         print("rehearsal finished, exit status", rc)
         sys.exit(rc)
