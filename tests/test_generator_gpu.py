@@ -756,7 +756,9 @@ def test_encoder_pretraining_step_matches_reference_vectors():
     img = torch.from_numpy(z["img"]).to(D).requires_grad_(True)
     enc.check_mask_layout = True
     pooled = enc(ids, mask, return_pooled=True)
-    assert pooled.dtype == torch.float32 and pooled.grad_fn is not None and "L2Norm" in type(pooled.grad_fn).__name__
+    # (the last node marks samples whose mask the kernels cannot honour; the L2 normalisation kernel is right behind it)
+    chain = [pooled.grad_fn] + [f for f, _ in pooled.grad_fn.next_functions if f is not None]
+    assert pooled.dtype == torch.float32 and any("L2Norm" in type(f).__name__ for f in chain)
     loss = crit(pooled, img)
     loss.backward()
     ref_pooled = torch.from_numpy(z["pooled"])
