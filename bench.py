@@ -14,7 +14,8 @@ backward (bucketed RCCL gradient all-reduce overlapped on a side stream when N >
 Prints ONE JSON line on rank 0 with `roofline` (contraction kernels vs the dense bf16 MFMA peak,
 measured with HIP events on the launch stream), and at N = 1 also `cpu_baseline` (the fp32 CPU oracle of the same
 step on a bounded sample), `sampler` (the 512x512 sampling loop: 16 images, classifier-free guidance, 50 DDIM steps,
-one HIP graph per step shape) and `lora` (the LoRA fine-tune step at the headline shape).
+one HIP graph per step shape), `lora` (the LoRA fine-tune step at the headline shape) and `e2e` (the train step from
+pixels and strings: auto-encoder, tokenizer and text encoder inside the step; never part of `value`).
 """
 import argparse
 import hashlib
@@ -51,6 +52,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the sampler and LoRA legs of the N = 1 line")
     ap.add_argument("--sampler-steps", type=int, default=50)
     ap.add_argument("--lora-steps", type=int, default=20)
+    ap.add_argument("--e2e-steps", type=int, default=10)
     ap.add_argument("--lora", action="store_true",
                     help="LoRA fine-tune step instead of the headline full fine-tune: frozen base, rank-4 adapters on "
                          "attn{1,2}.to_{q,k,v,out} (no cpu_baseline leg)")
@@ -159,6 +161,50 @@ def lora_leg(steps, B=32, L=32):
     return {"images_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "batch": B,
             "adapters": len(adapters), "trainable_params": int(tr.opt.flat.numel()), "hip_graph": True,
             "mfma_frac": 2 * FWD_GFLOP_PER_SAMPLE_256 * 1e9 * B * steps / dt / (MFMA_PEAK_TFLOPS * 1e12)}
+
+
+def e2e_leg(steps, B=32, side=256):
+    """The reference's whole loop body from pixels and strings (trainer.py:243-261 around image_generator.py:103-126):
+    `ImageGenerator.train_step(images, captions)` - frozen auto-encoder, tokenizer, frozen text encoder, noise and
+    timesteps drawn inside - then backward, clip and AdamW.  Eager step (captions of one length so that the shapes stay
+    static); the headline `value` excludes the auto-encoder and the text tower, this figure shows what they add."""
+    from image_generator_amd.generator import ImageGenerator
+    from image_generator_amd.trainer import DenoiserTrainer
+    torch.manual_seed(1234)
+    gen = ImageGenerator("cuda:0")
+    gen.train()
+    tr = DenoiserTrainer(gen.unet, lr=1e-4, weight_decay=1e-2, max_grad_norm=1.0)
+    images = torch.rand(B, 3, side, side, device="cuda:0") * 2 - 1
+    tags = ["1girl", "solo", "long_hair", "blue_sky", "outdoors", "smile", "school_uniform", "looking_at_viewer", "tree", "cloud"]
+    captions = [" ".join(tags[(i + j) % len(tags)] for j in range(10)) for i in range(B)]
+    step = lambda: tr.train_step_from(lambda: gen.train_step(images, captions, cond_dropout_prob=0.0))
+    for _ in range(3):
+        loss = step()
+    torch.cuda.synchronize()
+    probe = tr.opt.flat[:4096].clone()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the parts beside the denoiser step, timed alone on the same inputs
+    def timed(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+    with torch.no_grad():
+        vae_ms = timed(lambda: gen.vae.encode(images).latent_dist.sample())
+    text_ms = timed(lambda: gen.encode_text(captions, padding="longest"))
+    gn = tr.opt.grad_norm()
+    if not (math.isfinite(float(loss)) and math.isfinite(gn) and gn > 0) or torch.equal(probe, tr.opt.flat[:4096]):
+        raise RuntimeError("e2e leg: optimizer skipped or diverged")
+    return {"images_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "batch": B, "resolution": side,
+            "hip_graph": False, "vae_encode_ms": vae_ms, "tokenizer_text_encoder_ms": text_ms,
+            "includes": "ImageGenerator.train_step(images, captions): VAE encode + tokenizer + TextEncoder (8 layers, 768 wide) + "
+                        "noise / timesteps + denoiser forward; backward; clip + AdamW"}
 
 
 def cpu_baseline(args):
@@ -402,6 +448,8 @@ def main():
             out["sampler"] = sampler_leg(args.sampler_steps)
             torch.cuda.empty_cache()
             out["lora"] = lora_leg(args.lora_steps)
+            torch.cuda.empty_cache()
+            out["e2e"] = e2e_leg(args.e2e_steps)
             torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and not args.lora:
             out["cpu_baseline"] = cpu_baseline(args)

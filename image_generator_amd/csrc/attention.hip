@@ -24,6 +24,7 @@ struct AttnArgs {
     float drop_scale;
     int B, H, Nq, Nk, D;
     int ldq, ldk, ldv, ldo;
+    int lddk, lddv;        // row strides of dk / dv (backward): the gradients need not be laid out like k / v themselves
     float scale_log2;      // softmax scale * log2(e)
     float scale;
 };
@@ -460,8 +461,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
         }
     }
     if (k_ok) {
-        bf16_t* dK = p.dk + ((size_t)b * p.Nk + key) * p.ldk + h * p.D;
-        bf16_t* dV = p.dv + ((size_t)b * p.Nk + key) * p.ldv + h * p.D;
+        bf16_t* dK = p.dk + ((size_t)b * p.Nk + key) * p.lddk + h * p.D;
+        bf16_t* dV = p.dv + ((size_t)b * p.Nk + key) * p.lddv + h * p.D;
 #pragma unroll
         for (int db = 0; db < NO; ++db)
 #pragma unroll
@@ -736,27 +737,33 @@ int mi355_attention_bwd_train(const void* q, const void* k, const void* v, const
     a.dout = (const bf16_t*)dout; a.lse = (float*)lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk;
     a.dv = (bf16_t*)dv; a.kv_len = kv_len;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.lddk = ldk; a.lddv = ldv;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
     if (int rc = check_attn(a)) return rc;
     if (int rc = set_dropout(a, drop_p, seed)) return rc;
-    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 14.0 * B * H * (double)Nq * Nk * D);
+    // algorithmic work: dV, dP, dQ, dK are four products of 2 B H Nq Nk D (the recomputed scores are not counted)
+    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 8.0 * B * H * (double)Nq * Nk * D);
     if (a.drop_thresh == 0) return ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
     return ATTN_DISPATCH_DROP(launch_bwd_drop, a, (hipStream_t)stream);
 }
 
-// delta: scratch [B][H][Nq] floats.  dq uses ldq, dk ldk, dv ldv, dout/o use ldo.
+// delta: scratch [B][H][Nq] floats.  dq uses ldq, dout/o use ldo; dk / dv use lddk / lddv (0: ldk / ldv, the layout of
+// k / v themselves - keys and values that are column slices of a wider matrix can have contiguous gradients).
 int mi355_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                         float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int D, int ldq,
-                        int ldk, int ldv, int ldo, float scale, void* stream) {
+                        int ldk, int ldv, int ldo, int lddk, int lddv, float scale, void* stream) {
     if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv)
         return mi355_fail(MI355_ERR_ARG, "attention_bwd: null pointer");
     AttnArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
     a.dout = (const bf16_t*)dout; a.lse = (float*)lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk;
     a.dv = (bf16_t*)dv; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.lddk = lddk > 0 ? lddk : ldk; a.lddv = lddv > 0 ? lddv : ldv;
+    if ((a.lddk & 7) || (a.lddv & 7) || a.lddk < H * D || a.lddv < H * D)
+        return mi355_fail(MI355_ERR_ARG, "attention_bwd: dk / dv row strides must be multiples of 8 and hold H * D values");
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
     if (int rc = check_attn(a)) return rc;
-    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 14.0 * B * H * (double)Nq * Nk * D);
+    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 8.0 * B * H * (double)Nq * Nk * D);
     return ATTN_DISPATCH(launch_bwd, a, (hipStream_t)stream);
 }
 

@@ -819,6 +819,17 @@ __global__ __launch_bounds__(256) void cast_ranges_kernel(const long long* __res
     }
 }
 
+// dst <- src over n ranges in one launch: table (device) = n records of 3 int64 {source address, destination address,
+// bytes}, addresses 16-byte aligned, bytes a multiple of 16.  The packed operand of a product over several weights that
+// are not neighbours in memory (the text key / value projections of every cross-attention layer run as one product).
+__global__ __launch_bounds__(256) void copy_ranges_kernel(const long long* __restrict__ table) {
+    const char* src = (const char*)table[3 * blockIdx.y];
+    char* dst = (char*)table[3 * blockIdx.y + 1];
+    const size_t n16 = (size_t)table[3 * blockIdx.y + 2] >> 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        *(f32x4*)(dst + (i << 4)) = *(const f32x4*)(src + (i << 4));
+}
+
 extern "C" {
 
 #define ST ((hipStream_t)stream)
@@ -969,6 +980,11 @@ int mi355_zero_ranges(const long long* table, int n, void* stream) {
     if (!table || n <= 0) return mi355_fail(MI355_ERR_ARG, "zero_ranges: bad arguments");
     hipLaunchKernelGGL(zero_ranges_kernel, dim3(64, n), dim3(256), 0, ST, table);
     return mi355_check_launch("zero_ranges");
+}
+int mi355_copy_ranges(const long long* table, int n, int blocks_per_range, void* stream) {
+    if (!table || n <= 0 || blocks_per_range <= 0) return mi355_fail(MI355_ERR_ARG, "copy_ranges: bad arguments");
+    hipLaunchKernelGGL(copy_ranges_kernel, dim3(blocks_per_range, n), dim3(256), 0, ST, table);
+    return mi355_check_launch("copy_ranges");
 }
 int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, float* state,
                      long long n, void* stream) {

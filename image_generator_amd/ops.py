@@ -499,11 +499,11 @@ def attention_bwd(q, k, v, o, do, lse, heads, dq, dk, dv):
     Nk = k.shape[1]
     D = C // heads
     delta = torch.empty((B, heads, Nq), dtype=F32, device=q.device)
-    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    assert dq.stride(1) == q.stride(1)
     check(lib.mi355_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
                                   delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Nq, Nk, D,
-                                  q.stride(1), k.stride(1), v.stride(1), C, 1.0 / math.sqrt(D), _stream()),
-          "attention_bwd")
+                                  q.stride(1), k.stride(1), v.stride(1), C, dk.stride(1), dv.stride(1), 1.0 / math.sqrt(D),
+                                  _stream()), "attention_bwd")
 
 
 def gelu_bf16(x):
@@ -713,6 +713,44 @@ class SplitColsFn(torch.autograd.Function):
         B, dtype, dev = ctx.meta
         parts = [g if g is not None else torch.zeros((B, n), dtype=dtype, device=dev) for g, n in zip(grads, ctx.sizes)]
         return torch.cat(parts, dim=1), None
+
+
+class ContextKVFn(torch.autograd.Function):
+    """Text keys and values of SEVERAL cross-attention layers from one product: y = x W_all^T with W_all the row-stacked
+    (to_k | to_v) weights of every layer (a packed bf16 operand the owner keeps current); each layer receives its
+    [B, T, 2 C_i] column slice of y as a view.  Backward: x (the text states) needs no gradient; each layer's weight
+    gradient is its own job, exactly as if the layer had projected alone (its slice gradient arrives contiguous: the
+    attention backward kernels write dk / dv with strides of their own).
+    `weights`: (to_k.weight, to_v.weight) of every layer, in the order of `packs` (the layers' fused operand packs)."""
+
+    @staticmethod
+    def forward(ctx, x, w_all, packs, *weights):
+        from types import SimpleNamespace
+        B, T, K = x.shape
+        x2 = x.reshape(B * T, K)
+        y = gemm(x2, w_all)
+        ctx.save_for_backward(x2)
+        ctx.layers = [SimpleNamespace(pack=pk, xshape=x.shape, has_bias=False, has_res=False, bshapes=[], breq=[],
+                                      wshapes=[weights[2 * i].shape, weights[2 * i + 1].shape],
+                                      wreq=[weights[2 * i].requires_grad, weights[2 * i + 1].requires_grad])
+                      for i, pk in enumerate(packs)]
+        outs, c0 = [], 0
+        for pk in packs:
+            outs.append(y[:, c0:c0 + pk.n].view(B, T, pk.n))
+            c0 += pk.n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (x2,) = ctx.saved_tensors
+        dws = []
+        for ns, g in zip(ctx.layers, grads):
+            if g is None or not any(ns.wreq):
+                dws += [None, None]
+                continue
+            r = LinearFn._backward(ns, x2, g, (False, False, False, False, False))
+            dws += list(r[5:7])
+        return (None, None, None, *dws)
 
 
 class ConvFn(torch.autograd.Function):

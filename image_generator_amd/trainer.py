@@ -485,7 +485,10 @@ class DenoiserTrainer:
         pred = self.unet(noisy, t, encoder_hidden_states=ctx).sample
         return mse_loss(pred, noise)
 
-    def forward_backward(self, latents, noise, t, ctx):
+    def forward_backward(self, latents, noise, t, ctx, loss_fn=None):
+        """loss_fn: the caller builds the loss from the denoiser itself (see `train_step_from`)."""
+        if loss_fn is not None and self._fwd_graph is not None:
+            raise RuntimeError("forward_backward(loss_fn=...) runs the eager forward pass; drop the captured one first")
         if self._fwd_graph is not None:
             for dst, src in zip(self._static, (latents, noise, t, ctx)):
                 if dst.data_ptr() != src.data_ptr():
@@ -511,6 +514,8 @@ class DenoiserTrainer:
             if self._fwd_graph is not None:
                 self._fwd_graph.replay()                       # refreshes every tensor the recorded tape saved
                 loss = self._fwd_loss
+            elif loss_fn is not None:
+                loss = loss_fn()
             else:
                 loss = self._forward_loss(latents, noise, t, ctx)
             self._ops.set_wgrad_queue(self.wgrad_queue)        # weight gradients are deferred and batched
@@ -570,6 +575,22 @@ class DenoiserTrainer:
         if self._graph is not None:
             return self._replay(latents, noise, t, ctx, lr)
         loss = self.forward_backward(latents, noise, t, ctx)
+        reduced = self.reducer.stage_all if (self.reducer is not None and self.reducer.active) else None
+        self.opt.step(lr=lr, grad_prescale=1.0 / self.world, grad16=reduced, covered=self._covered)
+        self.step_count += 1
+        return loss
+
+    def train_step_from(self, loss_fn, epoch_float=None):
+        """One step on a loss the caller builds from this trainer's denoiser: the reference's loop body
+        (trainer.py:243-261) with `loss_fn = lambda: model.train_step(images, raw_text)` - pixels through the frozen
+        auto-encoder, captions through tokenizer and text encoder, noise and timesteps drawn inside
+        (image_generator.py:103-126) - followed by this trainer's backward pass (deferred, grouped weight gradients;
+        bucketed all-reduce when data-parallel), global-norm clip and fused AdamW.  Eager: the captured step takes
+        latents and text states (`train_step`)."""
+        if self._graph is not None:
+            raise RuntimeError("train_step_from(): this trainer replays a captured step on latents; build another trainer")
+        lr = None if epoch_float is None else cosine_warm_restarts_lr(self.base_lr, epoch_float)
+        loss = self.forward_backward(None, None, None, None, loss_fn=loss_fn)
         reduced = self.reducer.stage_all if (self.reducer is not None and self.reducer.active) else None
         self.opt.step(lr=lr, grad_prescale=1.0 / self.world, grad16=reduced, covered=self._covered)
         self.step_count += 1

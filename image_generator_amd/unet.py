@@ -28,7 +28,7 @@ import torch.nn as nn
 
 from ._lib import lib, check
 from . import ops
-from .ops import (BF16, F32, AttentionFn, CatNormShortcutFn, ConvFn, FeedForwardFn, GegluFn, GegluLinearFn, GroupNormFn, LayerNormFn, LinearFn,
+from .ops import (BF16, F32, AttentionFn, CatNormShortcutFn, ContextKVFn, ConvFn, FeedForwardFn, GegluFn, GegluLinearFn, GroupNormFn, LayerNormFn, LinearFn,
                   SiluF32ToBf16Fn, SplitColsFn, ToNCHWFn, ToNHWCFn, WeightPack, _stream)
 
 
@@ -265,6 +265,7 @@ class Attention(nn.Module):
         else:
             self.fused_pack.n, self.fused_pack.k = 3 * query_dim, query_dim
         self.lora_fused = None      # stacked views of the projections' adapters (set by the owning UNet)
+        self._ctx_kv = None         # this layer's slice of the model-wide text key / value projection (one forward pass)
 
     def _plain(self):
         return all(isinstance(m, HipLinear) for m in (self.to_q, self.to_k, self.to_v))
@@ -277,6 +278,10 @@ class Attention(nn.Module):
                 kv = None if cache is None else cache.get(id(self))
                 if kv is not None and (kv[0] is not context or kv[1].shape[:2] != context.shape[:2]):
                     kv = None
+                if kv is None and self._ctx_kv is not None:
+                    kv = (context, self._ctx_kv)
+                    if cache is not None:
+                        cache[id(self)] = kv
                 if kv is None:
                     kv = (context, LinearFn.apply(context, self.fused_pack, None, None, False, self.to_k.weight,
                                                   self.to_v.weight))
@@ -615,6 +620,22 @@ class UNet2DConditionModel(nn.Module):
                 S=S, r=r, alpha=float(ws[0].alpha), mods=ws, grad_dst=None,
                 A_all=flat[oa:oa + S * r * K].view(S * r, K), B_all=flat[ob:ob + S * C * r].view(S * C, r),
                 params=[p for w in ws for p in (w.lora_A.weight, w.lora_B.weight)])
+        # the text keys / values of every cross-attention layer multiply the same text states: one packed bf16 operand
+        # [sum 2 C_i][K] (refreshed with the other operand copies) lets ONE product compute all of them
+        self._ctx_layers, self._ctx_w16, self._ctx_table = [], None, None
+        cl = [m for m in self.modules() if isinstance(m, Attention) and m.is_cross and m._plain() and m.fused_pack.w16 is not None]
+        if (len(cl) > 1 and len({m.fused_pack.k for m in cl}) == 1 and all(m.fused_pack.n % 8 == 0 for m in cl)
+                and cl[0].fused_pack.k % 8 == 0 and os.environ.get("MI355_NO_CTX_KV_FUSION") != "1"):
+            K = cl[0].fused_pack.k
+            self._ctx_layers = cl
+            self._ctx_w16 = torch.zeros((sum(m.fused_pack.n for m in cl), K), dtype=BF16, device=dev)
+            rows, r0 = [], 0
+            for m in cl:
+                pk = m.fused_pack
+                rows.append([pk.w16.data_ptr(), self._ctx_w16.data_ptr() + 2 * r0 * K, 2 * pk.n * K])
+                r0 += pk.n
+            assert all(v % 16 == 0 for r in rows for v in r)
+            self._ctx_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._temb_pack = None
         tl = self._temb_layers
         if len(tl) > 1 and all(l.weight.numel() % 8 == 0 and l.bias.numel() % 8 == 0 for l in tl):
@@ -668,6 +689,8 @@ class UNet2DConditionModel(nn.Module):
                 pk.bias_pad[:pk.cout] = m.bias.data
         if self._tjobs.shape[0]:
             check(lib.mi355_transpose_batched(self._tjobs.data_ptr(), self._tjobs.shape[0], self._ttiles, s), "transpose_batched")
+        if self._ctx_table is not None:
+            check(lib.mi355_copy_ranges(self._ctx_table.data_ptr(), self._ctx_table.shape[0], 64, s), "copy_ranges")
         self._sig = self._signature()
 
     def _maybe_refresh(self):
@@ -873,6 +896,16 @@ class UNet2DConditionModel(nn.Module):
         if ctx.dtype != BF16:
             ctx = ctx.to(BF16)
         ctx = ctx.contiguous()
+        ctx_layers = self._ctx_layers
+        if ctx_layers:
+            cache = context_kv_cache.active if not torch.is_grad_enabled() else None
+            if cache is not None and all(id(m) in cache and cache[id(m)][0] is ctx for m in ctx_layers):
+                ctx_layers = []             # a sampling loop's later steps: every layer re-uses its cached slice
+            else:
+                kvs = ContextKVFn.apply(ctx, self._ctx_w16, [m.fused_pack for m in ctx_layers],
+                                        *[w for m in ctx_layers for w in (m.to_k.weight, m.to_v.weight)])
+                for m, kv in zip(ctx_layers, kvs):
+                    m._ctx_kv = kv
         x = ToNHWCFn.apply(sample, self.conv_in.pack.cin_pad)
         x = self.conv_in(x)
         skips = [x]
@@ -884,6 +917,8 @@ class UNet2DConditionModel(nn.Module):
             x = blk(x, skips, temb_act, ctx)
         for r in resnets:
             r._tproj = None
+        for m in ctx_layers:
+            m._ctx_kv = None
         x = self.conv_norm_out(x, silu=True)
         x = self.conv_out(x, out_fp32=True)
         return UNetOutput(ToNCHWFn.apply(x, cfg.out_channels))

@@ -184,9 +184,12 @@ int mi355_attention_fwd(const void* q, const void* k, const void* v, void* out, 
 int mi355_attention_fwd_masked(const void* q, const void* k, const void* v, void* out, float* lse, const int* kv_len,
                                int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale,
                                void* stream);
+/* Backward: delta [B][H][Nq] is scratch; dq uses ldq, dout / o use ldo.  dk / dv are written with row strides lddk / lddv
+ * (0: ldk / ldv): keys and values that are column slices of a wider matrix - the text keys / values of all
+ * cross-attention layers come out of one product - can have contiguous gradients. */
 int mi355_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                         float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int D, int ldq,
-                        int ldk, int ldv, int ldo, float scale, void* stream);
+                        int ldk, int ldv, int ldo, int lddk, int lddv, float scale, void* stream);
 
 /* Self-attention of the text encoder in TRAINING mode (encoder/text_encoder.py:16-23,31-34 as run by
  * encoder/train_encoder.py:103-105): the key-padding mask as valid key counts (kv_len, device int32 [B], or NULL) and
@@ -320,6 +323,11 @@ int mi355_sumsq_ranges(const long long* table, int n, float* out, void* stream);
 int mi355_zero_f32(float* p, long long n, void* stream);
 /* Zero n ranges in one launch: table (device, int64 pairs) = address (16-byte aligned), bytes (multiple of 16). */
 int mi355_zero_ranges(const long long* table, int n, void* stream);
+/* dst <- src over n ranges in one launch: table (device) = n records of 3 int64 {source address, destination address,
+ * bytes}; addresses 16-byte aligned, bytes a multiple of 16; blocks_per_range workgroups walk each range.  Packs the
+ * to_k / to_v weights of every cross-attention layer (operands of image_generator.py:124's denoiser call that all
+ * multiply the same text states) into one operand after an optimizer step, so that they run as ONE product. */
+int mi355_copy_ranges(const long long* table, int n, int blocks_per_range, void* stream);
 int mi355_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const float* hyper, float* state,
                      long long n, void* stream);
 /* The same two steps on bf16 gradients: a data-parallel step feeds the optimizer the all-reduced bf16 staging

@@ -995,3 +995,31 @@ def test_text_encoder_at_the_reference_head_width_96_matches_reference_vectors()
         return enc(ids, mask, return_pooled=True).detach()
     a, b, c = run(5), run(5), run(6)
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+
+
+def test_trainer_step_from_pixels_and_strings_equals_the_step_on_its_latents():
+    """`DenoiserTrainer.train_step_from(lambda: model.train_step(images, captions))` - the reference's loop body
+    (trainer.py:243-261) - draws noise and timesteps inside `ImageGenerator.train_step`; replaying the same draws by
+    hand and feeding latents, noise, timesteps and text states to `train_step` on an identical second model must give
+    the same loss, the same gradient norm and the same weights, bit for bit (same kernels, same order)."""
+    from image_generator_amd.trainer import DenoiserTrainer
+    gen_a, gen_b = _small_generator(3), _small_generator(3)
+    gen_b.load_state_dict(gen_a.state_dict())
+    gen_a.train(), gen_b.train()
+    tr_a = DenoiserTrainer(gen_a.unet, lr=1e-3)
+    tr_b = DenoiserTrainer(gen_b.unet, lr=1e-3)
+    images = torch.rand(4, 3, 64, 64, device=D) * 2 - 1
+    texts = ["1girl blue_hair smile", "cat", "landscape mountain sky cloud river", "2girls"]
+    for step in range(3):
+        torch.manual_seed(50 + step)
+        la = tr_a.train_step_from(lambda: gen_a.train_step(images, texts, cond_dropout_prob=0.0))
+        torch.manual_seed(50 + step)
+        latent = gen_b.vae.encode(images).latent_dist.sample() * 0.18215
+        t = torch.randint(0, 1000, (4,), device=D).long()
+        noise = torch.randn_like(latent)
+        torch.rand(1)
+        ctx = gen_b.encode_text(texts, padding="longest")
+        lb = tr_b.train_step(latent, noise, t, ctx)
+        assert float(la) == float(lb) and tr_a.opt.grad_norm() == tr_b.opt.grad_norm(), step
+    assert torch.equal(tr_a.opt.flat, tr_b.opt.flat) and tr_a.step_count == 3
+    assert tr_a.opt.skipped_steps() == 0

@@ -141,3 +141,50 @@ def test_unet_state_dict_roundtrip_and_refresh():
         hip2.load_state_dict(sd)
         y2 = hip2(x.to(d), t.to(d), ctx.to(d)).sample
     assert torch.equal(y2, y0)
+
+
+@pytest.mark.parametrize("cfg_name,B,hw,T", [("small", 3, 8, 9), ("sdlike", 2, 16, 77)])
+def test_text_keys_and_values_of_all_layers_from_one_product(cfg_name, B, hw, T, monkeypatch):
+    """The to_k / to_v projections of every cross-attention layer multiply the same text states and run as ONE product
+    on a packed operand (ops.ContextKVFn); with MI355_NO_CTX_KV_FUSION=1 each layer projects alone.  Same weights, same
+    inputs: outputs and every parameter gradient agree to bf16 rounding (the two forms accumulate in different tile
+    orders), the packed operand follows the weights through an optimizer-style update, and under no_grad with the
+    sampling loop's cache the product runs once."""
+    from image_generator_amd import ops
+    from image_generator_amd.unet import context_kv_cache
+    from image_generator_amd.ops import mse_loss
+    _, fused, rc = _pair(cfg_name)
+    monkeypatch.setenv("MI355_NO_CTX_KV_FUSION", "1")
+    _, plain, _ = _pair(cfg_name)
+    plain._ensure_flat()                    # (the switch is read when the flat storage is laid out)
+    monkeypatch.delenv("MI355_NO_CTX_KV_FUSION")
+    plain.load_state_dict(fused.state_dict())
+    x, t, ctx, noise = (v.cuda() for v in _inputs(rc, B, hw, T))
+    outs = []
+    for m in (fused, plain):
+        m._ensure_flat()
+        loss = mse_loss(m(x, t, encoder_hidden_states=ctx).sample, noise)
+        loss.backward()
+        outs.append(float(loss.detach()))
+    assert len(fused._ctx_layers) >= 2 and not plain._ctx_layers
+    assert abs(outs[0] - outs[1]) <= 2e-3 * abs(outs[1])
+    gp = dict(plain.named_parameters())
+    for n, p in fused.named_parameters():
+        if ".attn2.to_k." in n or ".attn2.to_v." in n or n.startswith("conv_in"):
+            assert _cos(p.grad, gp[n].grad) >= 0.999 and _rel(p.grad, gp[n].grad) <= 3e-2, n
+    # the packed operand is rebuilt with the other operand copies when a weight changes
+    with torch.no_grad():
+        fused._ctx_layers[1].to_v.weight.mul_(1.5)
+    fused._maybe_refresh()
+    r0 = fused._ctx_layers[0].fused_pack.n
+    pk = fused._ctx_layers[1].fused_pack
+    assert torch.equal(fused._ctx_w16[r0:r0 + pk.n], pk.w16.view(pk.n, pk.k))
+    # sampling loop: one product for the whole loop
+    calls = []
+    orig = ops.ContextKVFn.apply
+    monkeypatch.setattr(ops.ContextKVFn, "apply", staticmethod(lambda *a: (calls.append(1), orig(*a))[1]))
+    ctx16 = ctx.to(torch.bfloat16).contiguous()
+    with torch.no_grad(), context_kv_cache():
+        a = fused(x, t, encoder_hidden_states=ctx16).sample
+        b = fused(x, t, encoder_hidden_states=ctx16).sample
+    assert len(calls) == 1 and torch.equal(a, b)
