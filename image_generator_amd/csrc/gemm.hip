@@ -76,13 +76,27 @@ struct GemmArgs {
     // over (tap, channel) of the stored weight [C][taps][N] (C = g.C output channels of the layer, N its input
     // channels) with the taps in reverse order: k = tap * C + c reads row c, tap taps-1-tap.
     int bt, bt_ld;
+    // AMODE_DENSE_LN - LayerNorm folded into the products on either side of it (no pass over the activations):
+    //   producer: rowstat_out [M][tiles_n][2] receives, per row and column tile, the sum and the sum of squares of the
+    //             bf16 values this launch stores (the rows of the residual stream x it writes);
+    //   consumer: A is that x, un-normalised, Bw holds gamma-scaled weights W' = bf16(gamma (.) W); with the row's
+    //             mean and rstd from ln_part [M][ln_nparts][2] (the producer's partial sums, C = K values per row)
+    //             out = rstd * (A W'^T - mean * ln_cs) + bias,  ln_cs[n] = sum_k W'[n][k],  bias = W beta + b,
+    //             which is LayerNorm(x) W^T + b.
+    float* rowstat_out;
+    const float* ln_part;
+    const float* ln_cs;
+    int ln_nparts;
+    float ln_invc, ln_eps;
 };
 
 // AMODE_DENSE_LORA: dense A with the low-rank term in the epilogue - a kernel variant of its own so that every other
 // GEMM keeps the short epilogue (carrying the low-rank code path cost them 0.3 ms per training step)
-enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2, AMODE_DENSE_LORA = 3, AMODE_DENSE_CAT = 4 };
+// AMODE_DENSE_LN: dense A with the row statistics of a LayerNorm emitted and / or applied in the epilogue (see
+// GemmArgs) - again a kernel variant of its own, so that the other GEMMs' epilogues do not carry it
+enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2, AMODE_DENSE_LORA = 3, AMODE_DENSE_CAT = 4, AMODE_DENSE_LN = 5 };
 __host__ __device__ constexpr bool amode_dense(int amode) {
-    return amode == AMODE_DENSE || amode == AMODE_DENSE_LORA || amode == AMODE_DENSE_CAT;
+    return amode == AMODE_DENSE || amode == AMODE_DENSE_LORA || amode == AMODE_DENSE_CAT || amode == AMODE_DENSE_LN;
 }
 
 __device__ __forceinline__ float gemm_gelu_erf(float x) { return gelu_erf_f(x); }
@@ -161,9 +175,85 @@ __device__ __forceinline__ void lora_apply(const GemmArgs& p, int m, int n, floa
     }
 }
 
-template <int BN, int TM, int TN, int NTHREADS = 256, int BM = 128, bool LORA = false>
+// LayerNorm fold, consumer side (see GemmArgs): mean and rstd of the tile's BM rows from the producer's partial sums,
+// into LDS beyond the operand stages.  Called at kernel start - the loads' round trip hides behind the first k-tiles
+// (done in the epilogue it was exposed once per tile: +8 us per tile on the one-workgroup-per-CU kernel).
+template <int BM, int NTHREADS>
+__device__ __forceinline__ void ln_row_stats(const GemmArgs& p, int m0, float* rstat, int tid) {
+    if (p.ln_part == nullptr) return;
+    for (int r = tid; r < BM; r += NTHREADS) {
+        const int m = m0 + r;
+        float s0 = 0.f, s1 = 0.f;
+        if (m < p.M) {
+            const float* src = p.ln_part + (size_t)m * p.ln_nparts * 2;
+            for (int q = 0; q < p.ln_nparts; ++q) { const f32x2 pv = *(const f32x2*)(src + 2 * q); s0 += pv[0]; s1 += pv[1]; }
+        }
+        const float mean = s0 * p.ln_invc;
+        float var = s1 * p.ln_invc - mean * mean;
+        if (var < 0.f) var = 0.f;
+        rstat[2 * r] = mean;
+        rstat[2 * r + 1] = rsqrtf(var + p.ln_eps);
+    }
+}
+
+// LayerNorm fold, consumer side: column sum and bias of tile column `tid` (threads below BN), fetched at kernel start and
+// kept in two registers through the k-loop; the epilogue stages them in LDS.  Gated tiles: column c < BN/2 is hidden
+// unit f0 + c, column c >= BN/2 the gate of unit f0 + c - BN/2 (weight row F + that).
+template <int BN>
+__device__ __forceinline__ void ln_fold_column(const GemmArgs& p, int n0, int tid, float& ln_c, float& ln_b) {
+    ln_c = 0.f; ln_b = 0.f;
+    if (p.ln_part == nullptr || tid >= BN) return;
+    const int F = p.N >> 1, f0 = (n0 / BN) * (BN / 2);
+    const int n = p.geglu ? (tid < BN / 2 ? f0 + tid : F + f0 + tid - BN / 2) : n0 + tid;
+    const bool ok = p.geglu ? (tid < BN / 2 ? f0 + tid < F : f0 + tid - BN / 2 < F) : n < p.N;
+    if (ok) { ln_c = p.ln_cs[n]; if (p.bias) ln_b = p.bias[n]; }
+}
+
+// The same in two halves for the kernels with LDS to spare (one request burst at kernel start, no register and no
+// wait until the k-loop is over): the tile's rows of ln_part are ONE contiguous run of [BM][nparts][2] floats, fetched
+// by the LDS-DMA as lane-linear 1 KiB pieces (rows past M come back as zeros); ln_stats_finish turns them into mean and
+// rstd behind the k-loop's closing vmcnt(0) + barrier.  The requests are older than every operand request of the
+// wave, so the counted waits of the k-loops still retire what they mean to retire.
+template <int BM, int NW>
+__device__ __forceinline__ void ln_stats_request(const GemmArgs& p, int m0, char* raw, int wave, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (p.ln_part == nullptr) return;
+    const int rows = p.M - m0 < BM ? p.M - m0 : BM;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.ln_part + (size_t)m0 * p.ln_nparts * 2), 0, (unsigned)(rows * p.ln_nparts * 8), 0x00020000);
+    const int pieces = (BM * p.ln_nparts * 8 + 1023) >> 10;
+    for (int pc = wave; pc < pieces; pc += NW)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(raw + pc * 1024), 16,
+                                                 pc * 1024 + lane * 16, 0, 0, 0);
+#endif
+}
+// ALIAS: rstat overlays the fetched partial sums (the one-workgroup-per-CU kernel has 16 KiB beside its slabs and
+// [256][8][2] partial sums fill them): every thread sums its row first, a barrier, then the results are written.
+template <int BM, int NTHREADS, bool ALIAS = false>
+__device__ __forceinline__ void ln_stats_finish(const GemmArgs& p, const char* raw, float* rstat, int tid) {
+    static_assert(!ALIAS || BM <= NTHREADS, "aliased statistics: one row per thread");
+    if (p.ln_part == nullptr) return;           // (uniform over the workgroup)
+    for (int r = tid; r < (ALIAS ? NTHREADS : BM); r += NTHREADS) {
+        float s0 = 0.f, s1 = 0.f;
+        if (r < BM) {
+            const float* src = (const float*)raw + (size_t)r * p.ln_nparts * 2;
+            for (int q = 0; q < p.ln_nparts; ++q) { const f32x2 pv = *(const f32x2*)(src + 2 * q); s0 += pv[0]; s1 += pv[1]; }
+        }
+        if (ALIAS) __syncthreads();
+        if (r < BM) {
+            const float mean = s0 * p.ln_invc;
+            float var = s1 * p.ln_invc - mean * mean;
+            if (var < 0.f) var = 0.f;
+            rstat[2 * r] = mean;
+            rstat[2 * r + 1] = rsqrtf(var + p.ln_eps);
+        }
+    }
+}
+
+template <int BN, int TM, int TN, int NTHREADS = 256, int BM = 128, bool LORA = false, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], char* smem, int m0, int n0,
-                                              int split, int wm0, int wn0, int wave, int tid, int fr, int fq) {
+                                              int split, int wm0, int wn0, int wave, int tid, int fr, int fq,
+                                              const float* rstat = nullptr, float ln_c = 0.f, float ln_b = 0.f) {
     constexpr int EP_LD = BN + 4;
     // ---- split-K: raw fp32 partial slab, the reduce kernel applies the epilogue
     if (p.splitk > 1) {
@@ -203,6 +293,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             for (int i = tid; i < BN * 4; i += NTHREADS)
                 lf[(i & 3) * BN + (i >> 2)] = n0 + (i >> 2) < p.N ? p.lora_b[(size_t)n0 * 4 + i] : 0.f;
         }
+    }
+    // LayerNorm fold: the tile's column sums and biases staged once (lf is free in this variant) - loaded per 8-column
+    // chunk from global memory they put one more L1 round trip into every iteration of the chunk walk.
+    // Layout: cs [BN] | bias [BN]; gated tiles hold hidden units in columns [0, BN/2) and their gates behind them
+    const bool ln_fold = LN && p.ln_part != nullptr;
+    if (ln_fold && tid < BN) {      // (fetched by ln_fold_column() at kernel start: no round trip here)
+        lf[tid] = ln_c;
+        lf[BN + tid] = ln_b;
     }
     // low-rank activations of all BM rows, four per thread and 64-row group (zero past lora_ldt), fetched up front so
     // that their global-memory latency is paid once and not inside every group's barrier interval
@@ -254,7 +352,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { hv[q] *= p.alpha; gv[q] *= p.alpha; }
                 }
-                if (p.bias) {
+                if (ln_fold) {
+                    const float mu = rstat[2 * (h * 64 + row)], rs = rstat[2 * (h * 64 + row) + 1];
+                    const f32x4* ch = (const f32x4*)(lf + c8 * 8);
+                    const f32x4* cg = (const f32x4*)(lf + BN / 2 + c8 * 8);
+                    const f32x4* bh = (const f32x4*)(lf + BN + c8 * 8);
+                    const f32x4* bg = (const f32x4*)(lf + BN + BN / 2 + c8 * 8);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { hv[q] = (hv[q] - ch[q] * mu) * rs + bh[q]; gv[q] = (gv[q] - cg[q] * mu) * rs + bg[q]; }
+                } else if (p.bias) {
                     const f32x4* bh = (const f32x4*)(p.bias + f);
                     const f32x4* bg = (const f32x4*)(p.bias + F + f);
 #pragma unroll
@@ -277,8 +383,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
             continue;
         }
-        for (int idx = tid; idx < 64 * NC; idx += NTHREADS) {
-            const int row = idx / NC, c8 = idx - row * NC;
+        // chunk walk.  Plain: consecutive lanes run along a row's chunks and on into the next row.  LN: NTHREADS / 64
+        // adjacent lanes own a row and take every TPR-th chunk of it, so the row's sums stay in their registers
+        constexpr int TPR = NTHREADS / 64;
+        const int lrow = tid / TPR;
+        float rs0 = 0.f, rs1 = 0.f;
+        // (the row-owned walk in every kernel: 33.83 against 33.67 ms per train step, sampling step +-0 - kept to LN)
+        for (int it = LN ? tid % TPR : tid; it < (LN ? NC : 64 * NC); it += LN ? TPR : NTHREADS) {
+            const int row = LN ? lrow : it / NC, c8 = LN ? it : it - row * NC;
             const int m = m0 + h * 64 + row, n = n0 + c8 * 8;
             if (m >= p.M || n >= p.N) continue;
             float v[8];
@@ -286,7 +398,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             const f32x4 v1 = *(const f32x4*)(ep + row * EP_LD + c8 * 8 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = v0[e] * p.alpha; v[4 + e] = v1[e] * p.alpha; }
-            if (p.bias) {
+            if (ln_fold) {
+                const float mu = rstat[2 * (h * 64 + row)], rs = rstat[2 * (h * 64 + row) + 1];
+                const f32x4 c0 = *(const f32x4*)(lf + c8 * 8), c1 = *(const f32x4*)(lf + c8 * 8 + 4);
+                const f32x4 b0 = *(const f32x4*)(lf + BN + c8 * 8), b1 = *(const f32x4*)(lf + BN + c8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = (v[e] - mu * c0[e]) * rs + b0[e]; v[4 + e] = (v[4 + e] - mu * c1[e]) * rs + b1[e]; }
+            } else if (p.bias) {
                 const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
@@ -329,7 +447,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
                 *(bf16x8*)((bf16_t*)outp + (size_t)m * ldo + n - nsh) = ov;
+                if (LN && p.rowstat_out != nullptr) {      // sums of the values as stored
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float f = (float)ov[e]; rs0 += f; rs1 += f * f; }
+                }
             }
+        }
+        if (LN && p.rowstat_out != nullptr) {
+            // (LDS atomics per chunk cost more than the whole epilogue - up to 20 lanes on one address; a second pass
+            // over the staged rows cost a write-back, a barrier and a read)
+            static_assert((TPR & (TPR - 1)) == 0, "row sums: a power of two of lanes per row");
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) { rs0 += __shfl_xor(rs0, o); rs1 += __shfl_xor(rs1, o); }
+            const int m = m0 + h * 64 + lrow;
+            if (tid % TPR == 0 && m < p.M) *(f32x2*)(p.rowstat_out + ((size_t)m * p.tiles_n + n0 / BN) * 2) = f32x2{rs0, rs1};
         }
     }
 }
@@ -490,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         cur ^= 1;
     }
 
-    gemm_epilogue<BN, TM, TN, 256, 128, AMODE == AMODE_DENSE_LORA>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+    gemm_epilogue<BN, TM, TN, 256, 128, AMODE == AMODE_DENSE_LORA, AMODE == AMODE_DENSE_LN>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -561,6 +692,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     const int tile_m = lid % p.tiles_m;
     const int split = lid / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    float ln_c = 0.f, ln_b = 0.f;
+    if constexpr (AMODE == AMODE_DENSE_LN) {
+        ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
+        ln_row_stats<BM, NW * 64>(p, m0, (float*)(smem + NST * STAGE), tid);
+    }
     const int nkt_total = p.K / BK;
     const int kt_begin = split * p.kt_per_split;
     int kt_end = kt_begin + p.kt_per_split;
@@ -804,7 +940,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BN, TM, TN, NW * 64, BM, AMODE == AMODE_DENSE_LORA>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+    gemm_epilogue<BN, TM, TN, NW * 64, BM, AMODE == AMODE_DENSE_LORA, AMODE == AMODE_DENSE_LN>(
+        p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq, (const float*)(smem + NST * STAGE), ln_c, ln_b);
 #endif
 }
 
@@ -835,6 +972,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
     const int tile_n = lid % p.tiles_n;
     const int tile_m = lid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    constexpr int LN_STAT_OFF = (64 * 164 + 16 * 160 + 64 * 16) * 4;      // behind the stages and the epilogue staging
+    constexpr int LN_RAW_OFF = LN_STAT_OFF + 2 * BM * 4;                  // up to 16 KiB of partial sums ([256][8][2])
+    float ln_c = 0.f, ln_b = 0.f;
+    if constexpr (AMODE == AMODE_DENSE_LN) {
+        ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
+        ln_stats_request<BM, NW>(p, m0, smem + LN_RAW_OFF, wave, lane);
+    }
     const int nkt = p.K / BK;
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
@@ -976,7 +1120,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BN, TM, TN, 256, BM, AMODE == AMODE_DENSE_LORA>(p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq);
+    if constexpr (AMODE == AMODE_DENSE_LN) ln_stats_finish<BM, 256>(p, smem + LN_RAW_OFF, (float*)(smem + LN_STAT_OFF), tid);
+    gemm_epilogue<BN, TM, TN, 256, BM, AMODE == AMODE_DENSE_LORA, AMODE == AMODE_DENSE_LN>(
+        p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq, (const float*)(smem + LN_STAT_OFF), ln_c, ln_b);
 #endif
 }
 
@@ -1013,6 +1159,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsig
     const int tile_n = lid % p.tiles_n;
     const int tile_m = lid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    constexpr int LN_STAT_OFF = 4 * 36 * 1024;                            // behind the four slabs
+    constexpr int LN_RAW_OFF = LN_STAT_OFF;                               // up to 16 KiB of partial sums ([256][8][2]), overlaid
+    float ln_c = 0.f, ln_b = 0.f;
+    if constexpr (AMODE == AMODE_DENSE_LN) {
+        ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
+        ln_stats_request<BM, NW>(p, m0, smem + LN_RAW_OFF, wave, lane);
+    }
     const int nslab = p.K / BK;
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
@@ -1209,7 +1362,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsig
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BN, TM, TN, 512, BM, false>(p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq);
+    if constexpr (AMODE == AMODE_DENSE_LN) ln_stats_finish<BM, 512, true>(p, smem + LN_RAW_OFF, (float*)(smem + LN_STAT_OFF), tid);
+    gemm_epilogue<BN, TM, TN, 512, BM, false, AMODE == AMODE_DENSE_LN>(
+        p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq, (const float*)(smem + LN_STAT_OFF), ln_c, ln_b);
 #endif
 }
 
@@ -1340,7 +1495,8 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
 template <int AMODE>
 static int launch_gemm_wide(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
     // two 26 KiB stages; the epilogue re-uses them for 64 staging rows + low-rank factors + low-rank activations
-    constexpr int smem = (64 * 164 + 16 * 160 + 64 * 16) * 4;
+    // (+ the LayerNorm fold's row statistics: [256][2] + [64][2] floats)
+    constexpr int smem = (64 * 164 + 16 * 160 + 64 * 16 + (AMODE == AMODE_DENSE_LN ? 2 * 256 + 256 * 8 * 2 : 0)) * 4;
     static_assert(smem >= 2 * 26 * 1024, "stages must fit");
     static std::once_flag attr_set;
     std::call_once(attr_set, [] {
@@ -1352,8 +1508,10 @@ static int launch_gemm_wide(const GemmArgs& a, unsigned a_bytes, unsigned b_byte
 
 template <int AMODE>
 static int launch_gemm_pp(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
-    constexpr int smem = 4 * 36 * 1024;       // four slabs; the epilogue re-uses them (64 staging rows of 324 floats)
-    static_assert(smem >= (64 * 324 + 16 * 320 + 64 * 16) * 4, "epilogue staging must fit");
+    // four slabs; the epilogue re-uses them (64 staging rows of 324 floats); + [256][2] row statistics (LayerNorm fold)
+    // overlaid on the up to [256][8][2] partial sums fetched for them: all of the CU's 160 KiB
+    constexpr int smem = 4 * 36 * 1024 + (AMODE == AMODE_DENSE_LN ? 256 * 8 * 8 : 0);
+    static_assert(4 * 36 * 1024 >= (64 * 324 + 16 * 320 + 64 * 16) * 4, "epilogue staging must fit");
     static std::once_flag attr_set;
     std::call_once(attr_set, [] {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1367,7 +1525,8 @@ static int launch_gemm_pp(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes,
 // slab write + reduce pass.  Picks the split with the smallest estimated makespan.
 template <int BN, int AMODE, bool BT = false>
 static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes, hipStream_t s) {
-    constexpr int smem = 2 * (128 + BN) * 128;
+    constexpr int ln_extra = AMODE == AMODE_DENSE_LN ? 2 * 128 * 4 : 0;      // [128][2] row statistics behind the stages
+    constexpr int smem = 2 * (128 + BN) * 128 + ln_extra;
     static std::once_flag attr_set;
     std::call_once(attr_set, [] {
         (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 4, 128, 2, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1386,7 +1545,7 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
         return mi355_check_launch("gemm_dma_kernel");
     }
     if (grid <= nst3_max && grid <= nw8_max) {
-        constexpr int smem3 = 3 * (128 + BN) * 128;
+        constexpr int smem3 = 3 * (128 + BN) * 128 + ln_extra;
         static std::once_flag attr83_set;
         std::call_once(attr83_set, [] {
             (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AMODE, 8, 128, 3, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
@@ -1424,7 +1583,7 @@ static int pick_splitk(int tiles, int nkt, double out_elems, int bn) {
     return best;
 }
 
-static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_t s) {
+static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_t s, int* tiles_n_out = nullptr) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return mi355_fail(MI355_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     if ((a.N & 7) || (a.K & 7)) return mi355_fail(MI355_ERR_ARG, "gemm: N (%d) and K (%d) must be multiples of 8", a.N, a.K);
     if ((a.ldb & 7) || (a.ldo & 7) || (amode_dense(amode) && (a.lda & 7)))
@@ -1452,6 +1611,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     int sk = a.geglu ? 1 : pick_splitk(a.tiles_m * a.tiles_n, nkt, (double)a.M * a.N, bn);
     static const int force_sk = getenv("MI355_GEMM_SK") ? atoi(getenv("MI355_GEMM_SK")) : 0;     // tuning knob
     if (force_sk > 0 && !a.geglu) sk = force_sk < nkt ? force_sk : nkt;
+    if (amode == AMODE_DENSE_LN) sk = 1;        // the row statistics are emitted / applied by the tile epilogue only
     while (sk > 1 && (size_t)sk * a.M * a.N * sizeof(float) > ws_bytes) --sk;
     a.kt_per_split = (nkt + sk - 1) / sk;
     sk = (nkt + a.kt_per_split - 1) / a.kt_per_split;
@@ -1468,6 +1628,8 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     const bool dma_ok = !force_v1 && a.K % 64 == 0 && amode != AMODE_CONV_GENERIC && a_sz < 2.0e9 && b_sz < 2.0e9 &&
                         (double)a.M * (amode_dense(amode) ? a.lda : 1) < 1.0e9;
     if (a.geglu && !dma_ok) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_geglu: needs K %% 64 == 0 and operands < 2 GB");
+    if (amode == AMODE_DENSE_LN && (!dma_ok || bn != 160))
+        return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm (LayerNorm fold): needs N %% 160 == 0, K %% 64 == 0 and operands < 2 GB");
     if (a.bt) {         // k-major B: the 128 x 160 LDS-DMA kernel only
         if (!dma_ok || bn != 160 || (amode != AMODE_DENSE && amode != AMODE_CONV_FAST) || a.geglu || (a.bt_ld & 7) ||
             (amode == AMODE_CONV_FAST && (a.g.C % 64 || a.g.ups)))
@@ -1514,14 +1676,17 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
             a.tiles_n = tn;
         }
     }
+    if (tiles_n_out) *tiles_n_out = a.tiles_n;
     if (use_pp) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
-        rc = amode == AMODE_DENSE ? launch_gemm_pp<AMODE_DENSE>(a, ab, bb, s) : launch_gemm_pp<AMODE_CONV_FAST>(a, ab, bb, s);
+        rc = amode == AMODE_DENSE ? launch_gemm_pp<AMODE_DENSE>(a, ab, bb, s)
+             : amode == AMODE_DENSE_LN ? launch_gemm_pp<AMODE_DENSE_LN>(a, ab, bb, s) : launch_gemm_pp<AMODE_CONV_FAST>(a, ab, bb, s);
     } else if (dma_ok && a.bm == 256) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
         rc = amode == AMODE_DENSE ? launch_gemm_wide<AMODE_DENSE>(a, ab, bb, s)
              : amode == AMODE_DENSE_LORA ? launch_gemm_wide<AMODE_DENSE_LORA>(a, ab, bb, s)
-                                         : launch_gemm_wide<AMODE_CONV_FAST>(a, ab, bb, s);
+             : amode == AMODE_DENSE_LN ? launch_gemm_wide<AMODE_DENSE_LN>(a, ab, bb, s)
+                                       : launch_gemm_wide<AMODE_CONV_FAST>(a, ab, bb, s);
     } else if (amode == AMODE_DENSE_CAT) {
         if (!dma_ok || bn != 160)
             return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_cat: needs N %% 160 == 0, K1, K2 %% 64 == 0 and operands < 2 GB");
@@ -1531,7 +1696,8 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
 #define DISPATCH_DMA(BN) (amode == AMODE_DENSE ? launch_gemm_dma<BN, AMODE_DENSE>(a, ab, bb, s) \
                           : amode == AMODE_DENSE_LORA ? launch_gemm_dma<BN, AMODE_DENSE_LORA>(a, ab, bb, s) \
                                                : launch_gemm_dma<BN, AMODE_CONV_FAST>(a, ab, bb, s))
-        if (bn == 160) rc = DISPATCH_DMA(160);
+        if (amode == AMODE_DENSE_LN) rc = launch_gemm_dma<160, AMODE_DENSE_LN>(a, ab, bb, s);
+        else if (bn == 160) rc = DISPATCH_DMA(160);
         else if (bn == 64) rc = DISPATCH_DMA(64);
         else rc = DISPATCH_DMA(128);
 #undef DISPATCH_DMA
@@ -1677,6 +1843,39 @@ int mi355_gemm_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int 
     a.lora_ldt = lora_ldt; a.lora_seg = lora_seg; a.lora_rmajor = lora_rmajor; a.lora_t_bf16 = lora_t_bf16;
     a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
     return run_gemm(a, lora_t ? AMODE_DENSE_LORA : AMODE_DENSE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// LayerNorm folded into the two products around it (inference: no pass over the activations in between).
+//   mi355_gemm_rowstats_bf16: out [M][N] = A Bw^T + bias + residual as mi355_gemm_bf16, and rowstat [M][parts][2] =
+//       per row and column tile the sum and sum of squares of the stored bf16 values; *parts_out = the number of column
+//       tiles (N / 160 or N / 320, whichever tile the launcher took).  rowstat must hold M * (N / 160) * 2 floats.
+//   mi355_gemm_ln_bf16: out = LayerNorm(A) W^T + b from the un-normalised A [M][K] (K = the normalised width) and those
+//       partial sums: Bw = bf16(gamma (.) W) [N][K], colsum[n] = sum_k Bw[n][k] (fp32), bias = W beta + b
+//       (mi355_ln_fold_weight builds the three).  geglu != 0: N = 2F rows (hidden | gate), out [M][F] = h * gelu(g).
+int mi355_gemm_rowstats_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
+                             const float* bias, const void* residual, int ldr, float* rowstat, int* parts_out,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !Bw || !out || !rowstat || !parts_out) return mi355_fail(MI355_ERR_ARG, "gemm_rowstats: null pointer");
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.out = out; a.ldo = ldo; a.bias = bias; a.rowbias_div = 1; a.residual = (const bf16_t*)residual; a.ldr = ldr; a.alpha = 1.f;
+    a.rowstat_out = rowstat;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
+    return run_gemm(a, AMODE_DENSE_LN, workspace, workspace_bytes, (hipStream_t)stream, parts_out);
+}
+
+int mi355_gemm_ln_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
+                       const float* bias, const float* ln_part, int ln_nparts, const float* colsum, float eps, int geglu,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !Bw || !out || !ln_part || !colsum) return mi355_fail(MI355_ERR_ARG, "gemm_ln: null pointer");
+    if (ln_nparts < 1 || ln_nparts > 8 || ((uintptr_t)colsum & 15) || ((uintptr_t)ln_part & 15))
+        return mi355_fail(MI355_ERR_ARG, "gemm_ln: needs 1 to 8 partial sums per row, colsum and ln_part 16-byte aligned");
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.out = out; a.ldo = ldo; a.bias = bias; a.rowbias_div = 1; a.alpha = 1.f; a.geglu = geglu ? 1 : 0;
+    a.ln_part = ln_part; a.ln_nparts = ln_nparts; a.ln_cs = colsum; a.ln_invc = 1.f / (float)K; a.ln_eps = eps;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
+    return run_gemm(a, AMODE_DENSE_LN, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int mi355_gemm_skinny_bf16(const void* A, int lda, const void* Bw, int M, int W, int K, void* out, float alpha, void* stream) {

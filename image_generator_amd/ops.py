@@ -155,6 +155,55 @@ def conv2d_dgrad_bt(dy, w, cin, ksize, dil=False, out_hw=None):
     return dx
 
 
+def gemm_rowstats(a, w, bias=None, residual=None):
+    """(out, rowstat, parts): out = a w^T + bias + residual as `gemm`, and rowstat [M][parts][2] fp32 = per row and column
+    tile the sum and sum of squares of the bf16 values stored - the statistics a LayerNorm of `out` needs, produced by
+    the launch that writes `out` (see mi355_gemm_rowstats_bf16).  N % 160 == 0, K % 64 == 0."""
+    import ctypes
+    _req(a, BF16, "a"); _req(w, BF16, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=BF16, device=a.device)
+    stat = torch.empty((M, N // 160, 2), dtype=F32, device=a.device)
+    parts = ctypes.c_int(0)
+    ws = workspace(a.device)
+    check(lib.mi355_gemm_rowstats_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K, out.data_ptr(), N,
+                                       _ptr(bias), _ptr(residual), 0 if residual is None else residual.stride(0),
+                                       stat.data_ptr(), ctypes.byref(parts), ws.data_ptr(), ws.numel(), _stream()), "gemm_rowstats")
+    return out, stat.view(-1)[:M * parts.value * 2].view(M, parts.value, 2), parts.value
+
+
+def ln_fold_weight(weight, gamma, beta, bias=None, out=None):
+    """(wp, colsum, bias_out) for `gemm_ln`: the fp32 weight [N][K] of the layer behind a LayerNorm with that norm's
+    gamma / beta folded in (see mi355_ln_fold_weight).  out: the three destinations (row slices of larger buffers when
+    several layers share the norm and run as one product)."""
+    N, K = weight.shape
+    assert weight.dtype == F32 and weight.stride(1) == 1
+    if out is not None:
+        wp, cs, bo = out
+        assert wp.shape == (N, K) and wp.is_contiguous() and cs.numel() == N and bo.numel() == N
+    else:
+        wp = torch.empty((N, K), dtype=BF16, device=weight.device)
+        cs = torch.empty(N, dtype=F32, device=weight.device)
+        bo = torch.empty(N, dtype=F32, device=weight.device)
+    check(lib.mi355_ln_fold_weight(weight.data_ptr(), weight.stride(0), gamma.data_ptr(), beta.data_ptr(), _ptr(bias),
+                                   wp.data_ptr(), cs.data_ptr(), bo.data_ptr(), N, K, _stream()), "ln_fold_weight")
+    return wp, cs, bo
+
+
+def gemm_ln(a, wp, colsum, bias_out, rowstat, parts, eps, geglu=False):
+    """LayerNorm(a) W^T + b from the un-normalised a [M][K], the folded weight triple of `ln_fold_weight` and the row
+    statistics `gemm_rowstats` emitted with a; geglu: the gated form (N = 2F weight rows, out [M][F])."""
+    M, K = a.shape
+    N = wp.shape[0]
+    out = torch.empty((M, N // 2 if geglu else N), dtype=BF16, device=a.device)
+    ws = workspace(a.device)
+    check(lib.mi355_gemm_ln_bf16(a.data_ptr(), a.stride(0), wp.data_ptr(), wp.stride(0), M, N, K, out.data_ptr(), out.shape[1],
+                                 bias_out.data_ptr(), rowstat.data_ptr(), parts, colsum.data_ptr(), eps, int(geglu),
+                                 ws.data_ptr(), ws.numel(), _stream()), "gemm_ln")
+    return out
+
+
 def gemm_skinny(a, w, alpha=1.0):
     """bf16 [M, W] = alpha * a[M, K] @ w[W, K]^T for W in (8, 16): one launch, no split-K workspace."""
     M, K = a.shape

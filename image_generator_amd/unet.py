@@ -67,6 +67,9 @@ _COLSUM_FUSION = os.environ.get("MI355_NO_COLSUM_FUSION") != "1"
 # data gradients read the weights as stored instead of per-step transposed copies
 _BT_DGRAD = os.environ.get("MI355_NO_BT_DGRAD") != "1"
 
+# no-gradient calls: the transformer blocks' LayerNorms folded into the products around them
+_LN_FOLD = os.environ.get("MI355_NO_LN_FOLD") != "1"
+
 
 def _ceil8(n):
     return (n + 7) // 8 * 8
@@ -270,24 +273,29 @@ class Attention(nn.Module):
     def _plain(self):
         return all(isinstance(m, HipLinear) for m in (self.to_q, self.to_k, self.to_v))
 
+    def context_kv(self, context):
+        """The text keys | values [B, T, 2C] of this (plain, fused) cross-attention layer: the sampling loop's cached
+        projection, this forward pass's slice of the model-wide product, or a product of its own."""
+        cache = context_kv_cache.active if not torch.is_grad_enabled() else None
+        kv = None if cache is None else cache.get(id(self))
+        if kv is not None and (kv[0] is not context or kv[1].shape[:2] != context.shape[:2]):
+            kv = None
+        if kv is None and self._ctx_kv is not None:
+            kv = (context, self._ctx_kv)
+            if cache is not None:
+                cache[id(self)] = kv
+        if kv is None:
+            kv = (context, LinearFn.apply(context, self.fused_pack, None, None, False, self.to_k.weight,
+                                          self.to_v.weight))
+            if cache is not None:
+                cache[id(self)] = kv
+        return kv[1]
+
     def forward(self, x, context, residual):
         if self._plain() and self.fused_pack.w16 is not None:
             if self.is_cross:
                 q = self.to_q(x)
-                cache = context_kv_cache.active if not torch.is_grad_enabled() else None
-                kv = None if cache is None else cache.get(id(self))
-                if kv is not None and (kv[0] is not context or kv[1].shape[:2] != context.shape[:2]):
-                    kv = None
-                if kv is None and self._ctx_kv is not None:
-                    kv = (context, self._ctx_kv)
-                    if cache is not None:
-                        cache[id(self)] = kv
-                if kv is None:
-                    kv = (context, LinearFn.apply(context, self.fused_pack, None, None, False, self.to_k.weight,
-                                                  self.to_v.weight))
-                    if cache is not None:
-                        cache[id(self)] = kv
-                a = AttentionFn.apply(q, kv[1], None, self.heads)
+                a = AttentionFn.apply(q, self.context_kv(context), None, self.heads)
             else:
                 qkv = LinearFn.apply(x, self.fused_pack, None, None, False, self.to_q.weight, self.to_k.weight,
                                      self.to_v.weight)
@@ -350,6 +358,57 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = HipLayerNorm(dim)
         self.ff = FeedForward(dim)
 
+    # ---- no-gradient path with the three LayerNorms folded into the products around them ------------------------
+    def fold_ready(self, x):
+        """Whether `forward_folded` applies: no gradients, plain projections in whole 160-column tiles, enough rows
+        that no product would want a split contraction (the row statistics come out of the tile epilogue)."""
+        C = x.shape[-1]
+        a1, a2, g, o = self.attn1, self.attn2, self.ff.net[0].proj, self.ff.net[2]
+        return (not torch.is_grad_enabled() and _LN_FOLD and C % 160 == 0 and C % 64 == 0
+                and x.numel() // C >= 4096 and x.dtype == BF16
+                and a1._plain() and a2._plain() and a1.fused_pack.w16 is not None and a2.fused_pack.w16 is not None
+                and all(isinstance(m, HipLinear) and m.pack.w16 is not None for m in (a1.to_out[0], a2.to_out[0], a2.to_q, g, o))
+                and g.pack.k % 64 == 0 and (g.pack.n // 2) % 160 == 0)
+
+    def _folded(self):
+        """The folded operands (gamma-scaled bf16 weights, their column sums, beta-shifted biases) of the three
+        products that follow norm1 / norm2 / norm3, rebuilt when a weight or a norm parameter changed."""
+        a1, a2, g = self.attn1, self.attn2, self.ff.net[0].proj
+        src = (a1.to_q.weight, a1.to_k.weight, a1.to_v.weight, a2.to_q.weight, g.weight, g.bias, self.norm1.weight,
+               self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias)
+        sig = tuple(p._version for p in src) + (src[0].data_ptr(),)
+        if getattr(self, "_fold_sig", None) != sig:
+            C, dev = a1.to_q.weight.shape[1], a1.to_q.weight.device
+            wp = torch.empty((3 * C, C), dtype=BF16, device=dev)
+            cs, bo = torch.empty(3 * C, dtype=F32, device=dev), torch.empty(3 * C, dtype=F32, device=dev)
+            for i, m in enumerate((a1.to_q, a1.to_k, a1.to_v)):
+                sl = slice(i * C, (i + 1) * C)
+                ops.ln_fold_weight(m.weight.detach(), self.norm1.weight.detach(), self.norm1.bias.detach(), None,
+                                   out=(wp[sl], cs[sl], bo[sl]))
+            q = ops.ln_fold_weight(a2.to_q.weight.detach(), self.norm2.weight.detach(), self.norm2.bias.detach(), None)
+            f = ops.ln_fold_weight(g.weight.detach(), self.norm3.weight.detach(), self.norm3.bias.detach(), g.bias.detach())
+            self._fold, self._fold_sig = ((wp, cs, bo), q, f), sig
+        return self._fold
+
+    def forward_folded(self, x, context, stat, parts):
+        """x [B, N, C] un-normalised with the row statistics its producer emitted (ops.gemm_rowstats): the block without
+        a LayerNorm launch - every product that follows a norm applies it in its epilogue, every product that writes
+        the residual stream emits the next norm's statistics."""
+        B, N, C = x.shape
+        a1, a2, o = self.attn1, self.attn2, self.ff.net[2]
+        (w1, c1, b1), (w2, c2, b2), (w3, c3, b3) = self._folded()
+        x0 = x.view(B * N, C)
+        qkv = ops.gemm_ln(x0, w1, c1, b1, stat, parts, self.norm1.eps).view(B, N, 3 * C)
+        a = AttentionFn.apply(qkv, None, None, a1.heads).view(B * N, C)
+        p = a1.to_out[0].pack
+        x1, st1, p1 = ops.gemm_rowstats(a, p.w16.view(p.n, p.k), bias=a1.to_out[0].bias, residual=x0)
+        q = ops.gemm_ln(x1, w2, c2, b2, st1, p1, self.norm2.eps).view(B, N, C)
+        a = AttentionFn.apply(q, a2.context_kv(context), None, a2.heads).view(B * N, C)
+        p = a2.to_out[0].pack
+        x2, st2, p2 = ops.gemm_rowstats(a, p.w16.view(p.n, p.k), bias=a2.to_out[0].bias, residual=x1)
+        h = ops.gemm_ln(x2, w3, c3, b3, st2, p2, self.norm3.eps, geglu=True)
+        return ops.gemm(h, o.pack.w16.view(o.pack.n, o.pack.k), bias=o.bias, residual=x2).view(B, N, C)
+
     def forward(self, x, context):
         # each norm hands back the residual branch's view of its input: the two gradients meet inside the
         # normalisation's backward kernel instead of in a separate addition
@@ -372,6 +431,13 @@ class Transformer2D(nn.Module):
     def forward(self, x, context):
         B, H, W, C = x.shape
         h, x = self.norm(x, silu=False, passthrough=True)
+        blk0, pi = self.transformer_blocks[0], self.proj_in
+        if (len(self.transformer_blocks) == 1 and not pi.padded and pi.kernel_size == 1 and pi.pack.w16 is not None
+                and blk0.fold_ready(h)):
+            # sampling: proj_in emits the first norm's row statistics, the block runs without LayerNorm launches
+            h, stat, parts = ops.gemm_rowstats(h.view(-1, C), pi.pack.w16.view(pi.pack.n, pi.pack.k), bias=pi.bias)
+            h = blk0.forward_folded(h.view(B, H * W, C), context, stat, parts)
+            return self.proj_out(h.view(B, H, W, C), residual=x)
         h = self.proj_in(h).view(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)

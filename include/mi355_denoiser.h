@@ -111,6 +111,27 @@ int mi355_gemm_bt_bf16(const void* A, int lda, const void* W, int ldw, int M, in
 int mi355_conv2d_dgrad_bt_bf16(const void* dy, int B, int H, int W, int Cout, const void* w, int Cin, int ksize, int dil,
                                int Ho, int Wo, void* dx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* LayerNorm folded into the two products around it, for the no-gradient denoiser call of the sampling loop
+ * (image_generator.py:92-95: the transformer blocks' `norm1/2/3` followed by `attn1.to_q/k/v`, `attn2.to_q`, `ff.net.0.proj`
+ * in the third-party block): the normalised activations are never written or re-read.
+ *   mi355_gemm_rowstats_bf16: out [M][N] = A Bw^T + bias + residual (as mi355_gemm_bf16) and, from the same epilogue,
+ *       rowstat [M][parts][2] = per row and column tile the sum and the sum of squares of the bf16 values stored;
+ *       *parts_out (host int) = the number of column tiles taken (N / 160 or N / 320); rowstat holds M * (N / 160) * 2
+ *       floats.  N % 160 == 0, K % 64 == 0.
+ *   mi355_ln_fold_weight: from a layer's fp32 weight W [N][K] (row stride ldw), its bias (or NULL) and the norm's gamma /
+ *       beta [K]: Wp = bf16(gamma (.) W) [N][K], colsum[n] = sum_k Wp[n][k], bias_out[n] = sum_k beta[k] W[n][k] + bias[n].
+ *   mi355_gemm_ln_bf16: out = LayerNorm(A) W^T + b computed as rstd * (A Wp^T - mean * colsum) + bias_out, with mean and
+ *       rstd of each row of A [M][K] from ln_part [M][ln_nparts][2] (the partial sums above; K values per row, eps as
+ *       the norm's).  geglu != 0: N = 2F weight rows (hidden | gate), out [M][F] = h * gelu(g) as mi355_gemm_geglu_bf16. */
+int mi355_gemm_rowstats_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
+                             const float* bias, const void* residual, int ldr, float* rowstat, int* parts_out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int mi355_ln_fold_weight(const float* W, int ldw, const float* gamma, const float* beta, const float* bias, void* Wp,
+                         float* colsum, float* bias_out, int N, int K, void* stream);
+int mi355_gemm_ln_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
+                       const float* bias, const float* ln_part, int ln_nparts, const float* colsum, float eps, int geglu,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* 3x3 stride-2 convolution with one pixel of zero padding on the bottom and right only (the AutoencoderKL
  * down-sampler reached through image_generator.py:107-108 `self.vae.encode`): x [B][H][W][C] -> out [B][H/2][W/2][Cout]. */
 int mi355_conv2d_down_asym_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, void* out,

@@ -1174,3 +1174,49 @@ def test_model_trains_without_transposed_weight_copies():
     assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 50
     for n in grads[True]:
         assert rel_l2(grads[True][n], grads[False][n]) < 1e-5, n
+
+
+@pytest.mark.parametrize("case", [(32768, 640, 640, "pp"), (32768, 320, 960, "wide"), (16384, 320, 960, "dma4"),
+                                  (8192, 1280, 1280, "dma8"), (2048, 1280, 1280, "dma8x3"), (300, 320, 320, "ragged")])
+def test_layernorm_folded_into_the_products_around_it(case):
+    """mi355_gemm_rowstats_bf16 -> mi355_gemm_ln_bf16 (plain and gated) against the three separate steps (GEMM with
+    residual, LayerNorm kernel, GEMM / gated GEMM) and against fp32 math, on shapes that take each tile kernel.
+    (1) the emitting product stores the same bits as mi355_gemm_bf16 and its partial sums add up to the row sums of
+    those bits; (2) the folded product equals LayerNorm -> product to bf16 rounding of the normalised activations
+    (the fold never rounds them): relative L2 <= 1e-2 against the kernels, <= 1.5e-2 against fp32."""
+    from image_generator_amd import ops
+    d = dev()
+    M, C, N, _ = case
+    g = torch.Generator().manual_seed(M + C + N)
+    a = torch.randn(M, C, generator=g).to(BF).to(d)
+    w0 = (torch.randn(C, C, generator=g) * C ** -0.5).to(BF).to(d)
+    b0 = torch.randn(C, generator=g).to(d)
+    res = (torch.randn(M, C, generator=g) * 2 + 0.7).to(BF).to(d)          # rows with a mean: the fold subtracts it
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(d), (0.3 * torch.randn(C, generator=g)).to(d)
+    w1 = (torch.randn(N, C, generator=g) * C ** -0.5).to(d)
+    b1 = torch.randn(N, generator=g).to(d)
+    # (1) producer
+    x_ref = ops.gemm(a, w0, bias=b0, residual=res)
+    x, stat, parts = ops.gemm_rowstats(a, w0, bias=b0, residual=res)
+    assert torch.equal(x, x_ref) and parts in (C // 160, C // 320)
+    assert stat.shape == (M, parts, 2)
+    sums = stat.sum(1)
+    xf = x.float()
+    assert torch.allclose(sums[:, 0], xf.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sums[:, 1], (xf * xf).sum(1), rtol=1e-4, atol=1e-2)
+    # (2) consumer, plain
+    wp, cs, bo = ops.ln_fold_weight(w1, gamma, beta, b1)
+    assert torch.equal(wp, (w1 * gamma).to(BF)) and torch.allclose(cs, wp.float().sum(1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(bo, w1 @ beta + b1, rtol=1e-4, atol=1e-4)
+    y = ops.gemm_ln(x, wp, cs, bo, stat, parts, 1e-5)
+    y_k = ops.gemm(ops.layernorm_bf16(x, gamma, beta, 1e-5), w1.to(BF), bias=b1)
+    y_f = torch.nn.functional.layer_norm(xf, (C,), gamma, beta, 1e-5) @ w1.t() + b1
+    assert rel_l2(y, y_k) <= 1e-2 and rel_l2(y, y_f) <= 1.5e-2, (rel_l2(y, y_k), rel_l2(y, y_f))
+    assert rel_l2(y, y_f) <= 1.5 * rel_l2(y_k, y_f) + 1e-3          # the fold is not the less accurate of the two
+    # (3) consumer, gated: N = 2F
+    if N % 320 == 0:
+        F = N // 2
+        z = ops.gemm_ln(x, wp, cs, bo, stat, parts, 1e-5, geglu=True)
+        z_f = y_f[:, :F] * torch.nn.functional.gelu(y_f[:, F:])
+        z_k = ops.gemm_geglu(ops.layernorm_bf16(x, gamma, beta, 1e-5), w1.to(BF), b1)
+        assert z.shape == (M, F) and rel_l2(z, z_k) <= 1.5e-2 and rel_l2(z, z_f) <= 2e-2, (rel_l2(z, z_k), rel_l2(z, z_f))

@@ -188,3 +188,26 @@ def test_text_keys_and_values_of_all_layers_from_one_product(cfg_name, B, hw, T,
         a = fused(x, t, encoder_hidden_states=ctx16).sample
         b = fused(x, t, encoder_hidden_states=ctx16).sample
     assert len(calls) == 1 and torch.equal(a, b)
+
+
+def test_sampling_call_with_layernorms_folded_into_the_products(monkeypatch):
+    """Under no_grad at SD widths the transformer blocks run without LayerNorm launches (the norm is applied in the
+    epilogue of the product behind it, its statistics come out of the product in front of it).  Same model, same inputs,
+    fold on and off: the two outputs differ by bf16 rounding of the normalised activations only, and both sit at the
+    same distance from the fp32 oracle."""
+    import image_generator_amd.unet as U
+    from image_generator_amd import ops
+    ref, hip, rc = _pair("sdlike")
+    x, t, ctx, _ = _inputs(rc, 4, 32, 77)
+    with torch.no_grad():
+        want = ref(x, t, ctx).sample
+        calls = []
+        orig = ops.gemm_ln
+        monkeypatch.setattr(ops, "gemm_ln", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        folded = hip(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
+        n_folded = len(calls)
+        monkeypatch.setattr(U, "_LN_FOLD", False)
+        plain = hip(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
+    assert n_folded == 9 and len(calls) == 9            # three transformer blocks at 320 channels x three norms; none when off
+    assert _rel(folded, plain) <= 1e-2, _rel(folded, plain)
+    assert _rel(folded, want) <= 2e-2 and _rel(folded, want) <= 1.5 * _rel(plain, want) + 1e-3, (_rel(folded, want), _rel(plain, want))
