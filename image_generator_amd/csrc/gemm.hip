@@ -196,17 +196,17 @@ __device__ __forceinline__ void ln_row_stats(const GemmArgs& p, int m0, float* r
     }
 }
 
-// LayerNorm fold, consumer side: column sum and bias of tile column `tid` (threads below BN), fetched at kernel start and
-// kept in two registers through the k-loop; the epilogue stages them in LDS.  Gated tiles: column c < BN/2 is hidden
+// Bias (every kernel) and, for the LayerNorm fold's consumer side, column sum of tile column `tid` (threads below BN),
+// fetched at kernel start and kept in two registers through the k-loop; the epilogue stages them in LDS.  Gated tiles: column c < BN/2 is hidden
 // unit f0 + c, column c >= BN/2 the gate of unit f0 + c - BN/2 (weight row F + that).
 template <int BN>
 __device__ __forceinline__ void ln_fold_column(const GemmArgs& p, int n0, int tid, float& ln_c, float& ln_b) {
     ln_c = 0.f; ln_b = 0.f;
-    if (p.ln_part == nullptr || tid >= BN) return;
+    if ((p.ln_part == nullptr && p.bias == nullptr) || tid >= BN) return;
     const int F = p.N >> 1, f0 = (n0 / BN) * (BN / 2);
     const int n = p.geglu ? (tid < BN / 2 ? f0 + tid : F + f0 + tid - BN / 2) : n0 + tid;
     const bool ok = p.geglu ? (tid < BN / 2 ? f0 + tid < F : f0 + tid - BN / 2 < F) : n < p.N;
-    if (ok) { ln_c = p.ln_cs[n]; if (p.bias) ln_b = p.bias[n]; }
+    if (ok) { if (p.ln_part) ln_c = p.ln_cs[n]; if (p.bias) ln_b = p.bias[n]; }
 }
 
 // The same in two halves for the kernels with LDS to spare (one request burst at kernel start, no register and no
@@ -298,7 +298,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     // chunk from global memory they put one more L1 round trip into every iteration of the chunk walk.
     // Layout: cs [BN] | bias [BN]; gated tiles hold hidden units in columns [0, BN/2) and their gates behind them
     const bool ln_fold = LN && p.ln_part != nullptr;
-    if (ln_fold && tid < BN) {      // (fetched by ln_fold_column() at kernel start: no round trip here)
+    // the bias of the tile's columns is staged in LDS too (every kernel but the low-rank variant, whose factors live
+    // there): fetched per 8-column chunk it is one more L1 round trip in every iteration of the chunk walk - sampling
+    // step 33.9 -> 33.4 ms (its K = 320 products are all epilogue), train step +-0.  A per-sample bias staged the same
+    // way where a tile lies inside one sample: +0.1 ms on both, not kept.
+    const bool bias_lds = !LORA && p.bias != nullptr;
+    if ((ln_fold || bias_lds) && tid < BN) {      // (fetched by ln_fold_column() at kernel start: no round trip here)
         lf[tid] = ln_c;
         lf[BN + tid] = ln_b;
     }
@@ -360,6 +365,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     const f32x4* bg = (const f32x4*)(lf + BN + BN / 2 + c8 * 8);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { hv[q] = (hv[q] - ch[q] * mu) * rs + bh[q]; gv[q] = (gv[q] - cg[q] * mu) * rs + bg[q]; }
+                } else if (bias_lds) {
+                    const f32x4* bh = (const f32x4*)(lf + BN + c8 * 8);
+                    const f32x4* bg = (const f32x4*)(lf + BN + BN / 2 + c8 * 8);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { hv[q] += bh[q]; gv[q] += bg[q]; }
                 } else if (p.bias) {
                     const f32x4* bh = (const f32x4*)(p.bias + f);
                     const f32x4* bg = (const f32x4*)(p.bias + F + f);
@@ -404,6 +414,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 const f32x4 b0 = *(const f32x4*)(lf + BN + c8 * 8), b1 = *(const f32x4*)(lf + BN + c8 * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = (v[e] - mu * c0[e]) * rs + b0[e]; v[4 + e] = (v[4 + e] - mu * c1[e]) * rs + b1[e]; }
+            } else if (bias_lds) {
+                const f32x4 b0 = *(const f32x4*)(lf + BN + c8 * 8), b1 = *(const f32x4*)(lf + BN + c8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
             } else if (p.bias) {
                 const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
@@ -621,7 +635,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         cur ^= 1;
     }
 
-    gemm_epilogue<BN, TM, TN, 256, 128, AMODE == AMODE_DENSE_LORA, AMODE == AMODE_DENSE_LN>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq);
+    float ln_c = 0.f, ln_b = 0.f;
+    if constexpr (AMODE != AMODE_DENSE_LORA) ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
+    gemm_epilogue<BN, TM, TN, 256, 128, AMODE == AMODE_DENSE_LORA, AMODE == AMODE_DENSE_LN>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq,
+                                                                                           nullptr, ln_c, ln_b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -693,10 +710,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     const int split = lid / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     float ln_c = 0.f, ln_b = 0.f;
-    if constexpr (AMODE == AMODE_DENSE_LN) {
-        ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
-        ln_row_stats<BM, NW * 64>(p, m0, (float*)(smem + NST * STAGE), tid);
-    }
+    if constexpr (AMODE != AMODE_DENSE_LORA) ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
+    if constexpr (AMODE == AMODE_DENSE_LN) ln_row_stats<BM, NW * 64>(p, m0, (float*)(smem + NST * STAGE), tid);
     const int nkt_total = p.K / BK;
     const int kt_begin = split * p.kt_per_split;
     int kt_end = kt_begin + p.kt_per_split;
@@ -975,10 +990,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
     constexpr int LN_STAT_OFF = (64 * 164 + 16 * 160 + 64 * 16) * 4;      // behind the stages and the epilogue staging
     constexpr int LN_RAW_OFF = LN_STAT_OFF + 2 * BM * 4;                  // up to 16 KiB of partial sums ([256][8][2])
     float ln_c = 0.f, ln_b = 0.f;
-    if constexpr (AMODE == AMODE_DENSE_LN) {
-        ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
-        ln_stats_request<BM, NW>(p, m0, smem + LN_RAW_OFF, wave, lane);
-    }
+    if constexpr (AMODE != AMODE_DENSE_LORA) ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
+    if constexpr (AMODE == AMODE_DENSE_LN) ln_stats_request<BM, NW>(p, m0, smem + LN_RAW_OFF, wave, lane);
     const int nkt = p.K / BK;
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
@@ -1162,10 +1175,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsig
     constexpr int LN_STAT_OFF = 4 * 36 * 1024;                            // behind the four slabs
     constexpr int LN_RAW_OFF = LN_STAT_OFF;                               // up to 16 KiB of partial sums ([256][8][2]), overlaid
     float ln_c = 0.f, ln_b = 0.f;
-    if constexpr (AMODE == AMODE_DENSE_LN) {
-        ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
-        ln_stats_request<BM, NW>(p, m0, smem + LN_RAW_OFF, wave, lane);
-    }
+    if constexpr (AMODE != AMODE_DENSE_LORA) ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
+    if constexpr (AMODE == AMODE_DENSE_LN) ln_stats_request<BM, NW>(p, m0, smem + LN_RAW_OFF, wave, lane);
     const int nslab = p.K / BK;
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
