@@ -83,6 +83,11 @@ struct GemmArgs {
     //             mean and rstd from ln_part [M][ln_nparts][2] (the producer's partial sums, C = K values per row)
     //             out = rstd * (A W'^T - mean * ln_cs) + bias,  ln_cs[n] = sum_k W'[n][k],  bias = W beta + b,
     //             which is LayerNorm(x) W^T + b.
+    // GroupNorm statistics out of the producing epilogue (AMODE_DENSE_LN / AMODE_CONV_GS): gstat_out [tiles_m][N / gs_unit][2]
+    // receives, per row tile and per run of gs_unit (8 or 10) adjacent output channels, the sum and the sum of squares of
+    // the bf16 values this launch stores.  A row tile must lie inside one sample; the consumer's groups are whole runs.
+    float* gstat_out;
+    int gs_unit;
     float* rowstat_out;
     const float* ln_part;
     const float* ln_cs;
@@ -94,7 +99,11 @@ struct GemmArgs {
 // GEMM keeps the short epilogue (carrying the low-rank code path cost them 0.3 ms per training step)
 // AMODE_DENSE_LN: dense A with the row statistics of a LayerNorm emitted and / or applied in the epilogue (see
 // GemmArgs) - again a kernel variant of its own, so that the other GEMMs' epilogues do not carry it
-enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2, AMODE_DENSE_LORA = 3, AMODE_DENSE_CAT = 4, AMODE_DENSE_LN = 5 };
+// AMODE_CONV_GS: the LDS-DMA convolution whose epilogue also emits GroupNorm statistics (gstat_out); dense products that
+// emit them run as AMODE_DENSE_LN
+enum { AMODE_DENSE = 0, AMODE_CONV_FAST = 1, AMODE_CONV_GENERIC = 2, AMODE_DENSE_LORA = 3, AMODE_DENSE_CAT = 4, AMODE_DENSE_LN = 5,
+       AMODE_CONV_GS = 6 };
+__host__ __device__ constexpr bool amode_stats(int amode) { return amode == AMODE_DENSE_LN || amode == AMODE_CONV_GS; }
 __host__ __device__ constexpr bool amode_dense(int amode) {
     return amode == AMODE_DENSE || amode == AMODE_DENSE_LORA || amode == AMODE_DENSE_CAT || amode == AMODE_DENSE_LN;
 }
@@ -326,6 +335,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             tpre[h] = t4;
         }
     }
+    constexpr int TPR = NTHREADS / 64;                          // lanes per row of the row-owned chunk walk (LN variants)
+    // GroupNorm statistics: after each 64-row group the values as stored (written back into the staging rows) are added
+    // up by column - a thread owns four adjacent columns of every RP-th row - so eight registers hold its sums over the
+    // tile (per-chunk sums kept by the lanes that store the chunks took 20 registers and spilled in the 256-register kernels)
+    f32x4 gq0 = {0.f, 0.f, 0.f, 0.f}, gq1 = {0.f, 0.f, 0.f, 0.f};
+    const bool gs_emit = LN && p.gstat_out != nullptr;
     for (int h = 0; h < BM / 64; ++h) {
         __syncthreads();
         if (lora_lds && tid < 256) *(f32x4*)(lt + (tid >> 2) * 16 + (tid & 3) * 4) = tpre[h];
@@ -393,12 +408,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
             continue;
         }
-        // chunk walk.  Plain: consecutive lanes run along a row's chunks and on into the next row.  LN: NTHREADS / 64
-        // adjacent lanes own a row and take every TPR-th chunk of it, so the row's sums stay in their registers
-        constexpr int TPR = NTHREADS / 64;
+        // chunk walk.  Plain: consecutive lanes run along a row's chunks and on into the next row.  LN (the variants that
+        // emit statistics): NTHREADS / 64 adjacent lanes own a row and take every TPR-th chunk of it, so the row's sums
+        // - and, over the tile's row groups, each chunk's column sums - stay in their registers
+        // (the row-owned walk in every kernel: 33.83 against 33.67 ms per train step, sampling step +-0 - kept to LN)
         const int lrow = tid / TPR;
         float rs0 = 0.f, rs1 = 0.f;
-        // (the row-owned walk in every kernel: 33.83 against 33.67 ms per train step, sampling step +-0 - kept to LN)
         for (int it = LN ? tid % TPR : tid; it < (LN ? NC : 64 * NC); it += LN ? TPR : NTHREADS) {
             const int row = LN ? lrow : it / NC, c8 = LN ? it : it - row * NC;
             const int m = m0 + h * 64 + row, n = n0 + c8 * 8;
@@ -465,6 +480,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float f = (float)ov[e]; rs0 += f; rs1 += f * f; }
                 }
+                if (gs_emit) {
+                    float* er = ep + row * EP_LD + c8 * 8;
+                    *(f32x4*)er = f32x4{(float)ov[0], (float)ov[1], (float)ov[2], (float)ov[3]};
+                    *(f32x4*)(er + 4) = f32x4{(float)ov[4], (float)ov[5], (float)ov[6], (float)ov[7]};
+                }
             }
         }
         if (LN && p.rowstat_out != nullptr) {
@@ -475,6 +495,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             for (int o = TPR / 2; o > 0; o >>= 1) { rs0 += __shfl_xor(rs0, o); rs1 += __shfl_xor(rs1, o); }
             const int m = m0 + h * 64 + lrow;
             if (tid % TPR == 0 && m < p.M) *(f32x2*)(p.rowstat_out + ((size_t)m * p.tiles_n + n0 / BN) * 2) = f32x2{rs0, rs1};
+        }
+        if (gs_emit) {
+            // thread (q, rp): columns 4q .. 4q + 3 of rows rp, rp + RP, ...: one 16-byte LDS read per row
+            constexpr int NQ = BN / 4, RP = NTHREADS / NQ >= 4 ? 4 : (NTHREADS / NQ >= 2 ? 2 : 1);
+            __syncthreads();
+            const int q = tid % NQ, rp = tid / NQ;
+            if (rp < RP) {
+                const int nrow = p.M - m0 - h * 64 < 64 ? p.M - m0 - h * 64 : 64;
+#pragma unroll 4
+                for (int r = rp; r < nrow; r += RP) {
+                    const f32x4 f = *(const f32x4*)(ep + r * EP_LD + 4 * q);
+                    gq0 += f;
+                    gq1 += f * f;
+                }
+            }
+        }
+    }
+    if (gs_emit) {
+        // columns -> runs of gs_unit columns through LDS, one lane per run
+        constexpr int NQ = BN / 4, RP = NTHREADS / NQ >= 4 ? 4 : (NTHREADS / NQ >= 2 ? 2 : 1);
+        __syncthreads();
+        if (tid < NQ * RP) {            // [RP][BN] sums, then [RP][BN] sums of squares
+            *(f32x4*)(ep + (tid / NQ) * BN + 4 * (tid % NQ)) = gq0;
+            *(f32x4*)(ep + (RP + tid / NQ) * BN + 4 * (tid % NQ)) = gq1;
+        }
+        __syncthreads();
+        const int u = p.gs_unit;
+        if (tid < BN / u && n0 + tid * u < p.N) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int c = tid * u; c < tid * u + u; ++c)
+                for (int r = 0; r < RP; ++r) { s0 += ep[r * BN + c]; s1 += ep[(RP + r) * BN + c]; }
+            *(f32x2*)(p.gstat_out + ((size_t)(m0 / BM) * (p.N / u) + (n0 / u) + tid) * 2) = f32x2{s0, s1};
         }
     }
 }
@@ -637,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
     float ln_c = 0.f, ln_b = 0.f;
     if constexpr (AMODE != AMODE_DENSE_LORA) ln_fold_column<BN>(p, n0, tid, ln_c, ln_b);
-    gemm_epilogue<BN, TM, TN, 256, 128, AMODE == AMODE_DENSE_LORA, AMODE == AMODE_DENSE_LN>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq,
+    gemm_epilogue<BN, TM, TN, 256, 128, AMODE == AMODE_DENSE_LORA, amode_stats(AMODE)>(p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq,
                                                                                            nullptr, ln_c, ln_b);
 }
 
@@ -955,7 +1007,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BN, TM, TN, NW * 64, BM, AMODE == AMODE_DENSE_LORA, AMODE == AMODE_DENSE_LN>(
+    gemm_epilogue<BN, TM, TN, NW * 64, BM, AMODE == AMODE_DENSE_LORA, amode_stats(AMODE)>(
         p, acc, smem, m0, n0, split, wm0, wn0, wave, tid, fr, fq, (const float*)(smem + NST * STAGE), ln_c, ln_b);
 #endif
 }
@@ -1134,7 +1186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (AMODE == AMODE_DENSE_LN) ln_stats_finish<BM, 256>(p, smem + LN_RAW_OFF, (float*)(smem + LN_STAT_OFF), tid);
-    gemm_epilogue<BN, TM, TN, 256, BM, AMODE == AMODE_DENSE_LORA, AMODE == AMODE_DENSE_LN>(
+    gemm_epilogue<BN, TM, TN, 256, BM, AMODE == AMODE_DENSE_LORA, amode_stats(AMODE)>(
         p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq, (const float*)(smem + LN_STAT_OFF), ln_c, ln_b);
 #endif
 }
@@ -1374,7 +1426,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsig
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (AMODE == AMODE_DENSE_LN) ln_stats_finish<BM, 512, true>(p, smem + LN_RAW_OFF, (float*)(smem + LN_STAT_OFF), tid);
-    gemm_epilogue<BN, TM, TN, 512, BM, false, AMODE == AMODE_DENSE_LN>(
+    gemm_epilogue<BN, TM, TN, 512, BM, false, amode_stats(AMODE)>(
         p, acc, smem, m0, n0, 0, wm0, wn0, wave, tid, fr, fq, (const float*)(smem + LN_STAT_OFF), ln_c, ln_b);
 #endif
 }
@@ -1594,7 +1646,12 @@ static int pick_splitk(int tiles, int nkt, double out_elems, int bn) {
     return best;
 }
 
-static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_t s, int* tiles_n_out = nullptr) {
+// tiles_n_out: the column tiles taken (the partial sums per row of a LayerNorm-statistics producer).
+// gs_rows_out: GroupNorm statistics were asked for (gstat_out) - receives the rows per tile they were emitted for, or 0
+// when this launch could not emit them (split contraction, a tile that would span two samples, a fallback kernel): the
+// product then ran as its plain form and the caller takes the statistics pass.
+static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_t s, int* tiles_n_out = nullptr,
+                    int* gs_rows_out = nullptr) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return mi355_fail(MI355_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     if ((a.N & 7) || (a.K & 7)) return mi355_fail(MI355_ERR_ARG, "gemm: N (%d) and K (%d) must be multiples of 8", a.N, a.K);
     if ((a.ldb & 7) || (a.ldo & 7) || (amode_dense(amode) && (a.lda & 7)))
@@ -1622,7 +1679,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     int sk = a.geglu ? 1 : pick_splitk(a.tiles_m * a.tiles_n, nkt, (double)a.M * a.N, bn);
     static const int force_sk = getenv("MI355_GEMM_SK") ? atoi(getenv("MI355_GEMM_SK")) : 0;     // tuning knob
     if (force_sk > 0 && !a.geglu) sk = force_sk < nkt ? force_sk : nkt;
-    if (amode == AMODE_DENSE_LN) sk = 1;        // the row statistics are emitted / applied by the tile epilogue only
+    if (amode == AMODE_DENSE_LN && (a.rowstat_out || a.ln_part)) sk = 1;   // row statistics: emitted / applied by the tile epilogue only
     while (sk > 1 && (size_t)sk * a.M * a.N * sizeof(float) > ws_bytes) --sk;
     a.kt_per_split = (nkt + sk - 1) / sk;
     sk = (nkt + a.kt_per_split - 1) / a.kt_per_split;
@@ -1639,7 +1696,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     const bool dma_ok = !force_v1 && a.K % 64 == 0 && amode != AMODE_CONV_GENERIC && a_sz < 2.0e9 && b_sz < 2.0e9 &&
                         (double)a.M * (amode_dense(amode) ? a.lda : 1) < 1.0e9;
     if (a.geglu && !dma_ok) return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_geglu: needs K %% 64 == 0 and operands < 2 GB");
-    if (amode == AMODE_DENSE_LN && (!dma_ok || bn != 160))
+    if (amode == AMODE_DENSE_LN && (a.rowstat_out || a.ln_part) && (!dma_ok || bn != 160))
         return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm (LayerNorm fold): needs N %% 160 == 0, K %% 64 == 0 and operands < 2 GB");
     if (a.bt) {         // k-major B: the 128 x 160 LDS-DMA kernel only
         if (!dma_ok || bn != 160 || (amode != AMODE_DENSE && amode != AMODE_CONV_FAST) || a.geglu || (a.bt_ld & 7) ||
@@ -1687,17 +1744,30 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
             a.tiles_n = tn;
         }
     }
+    if (a.gstat_out) {
+        // statistics per (row tile, run of channels): only from an unsplit tile epilogue whose rows lie in one sample
+        const bool ok = dma_ok && bn == 160 && sk == 1 && a.rowbias_div % a.bm == 0 && a.M % a.bm == 0 &&
+                        (a.gs_unit == 8 || a.gs_unit == 10) && !a.geglu;
+        if (!ok) {
+            a.gstat_out = nullptr;
+            if (amode == AMODE_CONV_GS) amode = AMODE_CONV_FAST;
+            else if (amode == AMODE_DENSE_LN && !a.rowstat_out && !a.ln_part) amode = AMODE_DENSE;
+        }
+        if (gs_rows_out) *gs_rows_out = ok ? a.bm : 0;
+    }
     if (tiles_n_out) *tiles_n_out = a.tiles_n;
     if (use_pp) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
         rc = amode == AMODE_DENSE ? launch_gemm_pp<AMODE_DENSE>(a, ab, bb, s)
-             : amode == AMODE_DENSE_LN ? launch_gemm_pp<AMODE_DENSE_LN>(a, ab, bb, s) : launch_gemm_pp<AMODE_CONV_FAST>(a, ab, bb, s);
+             : amode == AMODE_DENSE_LN ? launch_gemm_pp<AMODE_DENSE_LN>(a, ab, bb, s)
+             : amode == AMODE_CONV_GS ? launch_gemm_pp<AMODE_CONV_GS>(a, ab, bb, s) : launch_gemm_pp<AMODE_CONV_FAST>(a, ab, bb, s);
     } else if (dma_ok && a.bm == 256) {
         const unsigned ab = (unsigned)a_sz, bb = (unsigned)b_sz;
         rc = amode == AMODE_DENSE ? launch_gemm_wide<AMODE_DENSE>(a, ab, bb, s)
              : amode == AMODE_DENSE_LORA ? launch_gemm_wide<AMODE_DENSE_LORA>(a, ab, bb, s)
              : amode == AMODE_DENSE_LN ? launch_gemm_wide<AMODE_DENSE_LN>(a, ab, bb, s)
-                                       : launch_gemm_wide<AMODE_CONV_FAST>(a, ab, bb, s);
+             : amode == AMODE_CONV_GS ? launch_gemm_wide<AMODE_CONV_GS>(a, ab, bb, s)
+                                      : launch_gemm_wide<AMODE_CONV_FAST>(a, ab, bb, s);
     } else if (amode == AMODE_DENSE_CAT) {
         if (!dma_ok || bn != 160)
             return mi355_fail(MI355_ERR_UNSUPPORTED, "gemm_cat: needs N %% 160 == 0, K1, K2 %% 64 == 0 and operands < 2 GB");
@@ -1708,6 +1778,7 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
                           : amode == AMODE_DENSE_LORA ? launch_gemm_dma<BN, AMODE_DENSE_LORA>(a, ab, bb, s) \
                                                : launch_gemm_dma<BN, AMODE_CONV_FAST>(a, ab, bb, s))
         if (amode == AMODE_DENSE_LN) rc = launch_gemm_dma<160, AMODE_DENSE_LN>(a, ab, bb, s);
+        else if (amode == AMODE_CONV_GS) rc = launch_gemm_dma<160, AMODE_CONV_GS>(a, ab, bb, s);
         else if (bn == 160) rc = DISPATCH_DMA(160);
         else if (bn == 64) rc = DISPATCH_DMA(64);
         else rc = DISPATCH_DMA(128);
@@ -1915,10 +1986,10 @@ int mi355_gemm_geglu_bf16(const void* A, int lda, const void* Bw, int ldb, int M
     return run_gemm(a, AMODE_DENSE, nullptr, 0, (hipStream_t)stream);
 }
 
-int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, int ksize, int stride,
+static int conv2d_run(const void* x, int B, int H, int W, int C, const void* w, int Cout, int ksize, int stride,
                       int ups, int dil, int Ho, int Wo, void* out, int out_fp32, const float* bias,
-                      const float* rowbias, int ld_rowbias, const void* residual, float alpha, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+                      const float* rowbias, int ld_rowbias, const void* residual, float alpha, float* gstat, int gs_unit,
+                      int* gs_rows_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !out) return mi355_fail(MI355_ERR_ARG, "conv2d: null pointer");
     if (ksize != 1 && ksize != 3) return mi355_fail(MI355_ERR_UNSUPPORTED, "conv2d: ksize %d (1 or 3 supported)", ksize);
     if (stride != 1 && stride != 2) return mi355_fail(MI355_ERR_UNSUPPORTED, "conv2d: stride %d", stride);
@@ -1939,8 +2010,50 @@ int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, 
     a.out = out; a.ldo = Cout; a.out_fp32 = out_fp32; a.bias = bias; a.rowbias = rowbias; a.rowbias_div = Ho * Wo;
     a.ld_rowbias = ld_rowbias; a.residual = (const bf16_t*)residual; a.ldr = Cout; a.alpha = alpha;
     a.g = ConvGeom{B, H, W, C, Ho, Wo, stride, ups, dil, ksize, ksize / 2};
-    const int amode = (C % 64 == 0) ? AMODE_CONV_FAST : AMODE_CONV_GENERIC;
-    return run_gemm(a, amode, workspace, workspace_bytes, (hipStream_t)stream);
+    int amode = (C % 64 == 0) ? AMODE_CONV_FAST : AMODE_CONV_GENERIC;
+    if (gs_rows_out) *gs_rows_out = 0;
+    if (gstat && amode == AMODE_CONV_FAST && !out_fp32 && Cout % gs_unit == 0) {
+        a.gstat_out = gstat; a.gs_unit = gs_unit;
+        amode = AMODE_CONV_GS;
+    }
+    return run_gemm(a, amode, workspace, workspace_bytes, (hipStream_t)stream, nullptr, gs_rows_out);
+}
+
+int mi355_conv2d_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, int ksize, int stride,
+                      int ups, int dil, int Ho, int Wo, void* out, int out_fp32, const float* bias,
+                      const float* rowbias, int ld_rowbias, const void* residual, float alpha, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    return conv2d_run(x, B, H, W, C, w, Cout, ksize, stride, ups, dil, Ho, Wo, out, out_fp32, bias, rowbias, ld_rowbias, residual,
+                      alpha, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+// The same convolution / product with the statistics of a following GroupNorm out of its epilogue: gstat
+// [M / rows][Cout / unit][2] = per row tile (rows = *rows_out output rows, all of one sample) and run of `unit` (8 or 10)
+// adjacent output channels the sum and sum of squares of the bf16 values stored.  *rows_out = 0: this launch could not
+// emit them (it ran as the plain product; gstat is untouched).  gstat holds (M / 128) * (Cout / unit) * 2 floats.
+int mi355_conv2d_gnstats_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, int ksize, int stride,
+                              int ups, int Ho, int Wo, void* out, const float* bias, const float* rowbias, int ld_rowbias,
+                              const void* residual, float* gstat, int unit, int* rows_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!gstat || !rows_out || (unit != 8 && unit != 10)) return mi355_fail(MI355_ERR_ARG, "conv2d_gnstats: gstat, rows_out, unit 8 or 10");
+    return conv2d_run(x, B, H, W, C, w, Cout, ksize, stride, ups, 0, Ho, Wo, out, 0, bias, rowbias, ld_rowbias, residual, 1.f, gstat,
+                      unit, rows_out, workspace, workspace_bytes, stream);
+}
+
+int mi355_gemm_gnstats_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
+                            const float* bias, const void* residual, int ldr, int rows_per_sample, float* gstat, int unit,
+                            int* rows_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !Bw || !out || !gstat || !rows_out || (unit != 8 && unit != 10) || rows_per_sample < 1)
+        return mi355_fail(MI355_ERR_ARG, "gemm_gnstats: null pointer, or unit not 8 / 10");
+    GemmArgs a = {};
+    a.A = (const bf16_t*)A; a.Bw = (const bf16_t*)Bw; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.out = out; a.ldo = ldo; a.bias = bias; a.rowbias_div = rows_per_sample; a.residual = (const bf16_t*)residual; a.ldr = ldr;
+    a.alpha = 1.f;
+    a.g = ConvGeom{0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
+    *rows_out = 0;
+    int amode = AMODE_DENSE;
+    if (N % unit == 0) { a.gstat_out = gstat; a.gs_unit = unit; amode = AMODE_DENSE_LN; }
+    return run_gemm(a, amode, workspace, workspace_bytes, (hipStream_t)stream, nullptr, rows_out);
 }
 
 // 3x3 stride-2 convolution whose zero padding is one pixel on the bottom and right only: Ho = H / 2 for even H.

@@ -168,15 +168,48 @@ __device__ __forceinline__ void gn_group_sums(const float* __restrict__ gpart, f
     __syncthreads();
 }
 
+// Statistics that the producer(s) of x emitted from their own epilogues (mi355_conv2d_gnstats_bf16 /
+// mi355_gemm_gnstats_bf16): per row tile and run of `unit` adjacent channels the sum and the sum of squares.  p1 covers
+// the first n1 runs of the channel axis (all of it, or the first source of a two-source input), p2 the other n2;
+// a sample has t1 (t2) row tiles: p[(b * t + tile) * n + run][2].
+struct GnPre {
+    const float* p1;
+    const float* p2;
+    int t1, t2, n1, n2, unit;
+};
+// gs[g] = {sum, sum of squares} of group g of sample b from those records (a group is cg / unit whole runs).
+__device__ __forceinline__ void gn_group_sums_pre(const GnPre& q, float* gs, int b, int G, int cg) {
+    const int per = cg / q.unit;
+    for (int i = threadIdx.x; i < G * 2; i += blockDim.x) {
+        const int g = i >> 1, k = i & 1;
+        float s = 0.f;
+        for (int r = g * per; r < (g + 1) * per; ++r) {
+            const bool first = r < q.n1;
+            const float* src = first ? q.p1 + ((size_t)b * q.t1 * q.n1 + r) * 2 + k : q.p2 + ((size_t)b * q.t2 * q.n2 + (r - q.n1)) * 2 + k;
+            const int t = first ? q.t1 : q.t2, n = first ? q.n1 : q.n2;
+            for (int t0 = 0; t0 < t; t0 += 8) {            // eight independent loads per round trip
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = t0 + u < t ? src[(size_t)(t0 + u) * n * 2] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+        }
+        gs[i] = s;
+    }
+    __syncthreads();
+}
+
 __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gpart, float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 bf16_t* __restrict__ y, int HW, int C, int G, int rows_per_block, int silu, float eps,
-                                const bf16_t* __restrict__ x2 = nullptr, int C1 = 0) {
+                                const bf16_t* __restrict__ x2 = nullptr, int C1 = 0, const GnPre pre = GnPre{}) {
     extern __shared__ float gs[];            // [G][2] -> mean, rstd
     const int nc = C >> 3;
     const int b = blockIdx.y;
     const int cg = C / G;
-    gn_group_sums(gpart, gs, b, gridDim.x, G);
+    if (pre.p1 != nullptr) gn_group_sums_pre(pre, gs, b, G, cg);
+    else gn_group_sums(gpart, gs, b, gridDim.x, G);
     const float inv_n = 1.f / ((float)HW * cg);
     float sc[8], sh[8];
     const int c8 = threadIdx.x % nc, rp = threadIdx.x / nc, rpar = blockDim.x / nc;
@@ -714,22 +747,28 @@ long long mi355_groupnorm_scratch_floats(int B, int HW, int C, int G) {
 }
 
 static int gn_fwd_launch(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* stats,
-                         float* scratch, int B, int HW, int C, int G, float eps, int silu, void* stream) {
+                         float* scratch, int B, int HW, int C, int G, float eps, int silu, void* stream,
+                         const GnPre* pre = nullptr) {
     int threads, rpar, rows, strips;
     if (int rc = gn_geometry(HW, C, G, &threads, &rpar, &rows, &strips)) return rc;
     hipStream_t st = (hipStream_t)stream;
     float* gpart = scratch;
-    ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * 3);
+    ProfScope prof(FAM_NORM, st, (double)B * HW * C * 2 * (pre ? 2 : 3));
     if (gn_small_fwd(HW, C, G)) {
         hipLaunchKernelGGL(gn_small_fwd_kernel, dim3(G, B), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, stats,
                            HW, C, G, silu, eps, (const bf16_t*)x2, C1);
         return mi355_check_launch("groupnorm_fwd(small)");
     }
+    if (pre) {          // the statistics exist already: the normalising pass alone
+        hipLaunchKernelGGL(gn_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st, (const bf16_t*)x,
+                           nullptr, stats, gamma, beta, (bf16_t*)y, HW, C, G, rows, silu, eps, (const bf16_t*)x2, C1, *pre);
+        return mi355_check_launch("groupnorm_fwd(pre)");
+    }
     const size_t sh = (size_t)threads * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(strips, B), dim3(threads), sh, st, (const bf16_t*)x, nullptr,
                        nullptr, nullptr, nullptr, gpart, nullptr, HW, C, G, rows, 0, (const bf16_t*)x2, C1);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(strips, B), dim3(threads), (size_t)G * 2 * sizeof(float), st, (const bf16_t*)x,
-                       gpart, stats, gamma, beta, (bf16_t*)y, HW, C, G, rows, silu, eps, (const bf16_t*)x2, C1);
+                       gpart, stats, gamma, beta, (bf16_t*)y, HW, C, G, rows, silu, eps, (const bf16_t*)x2, C1, GnPre{});
     return mi355_check_launch("groupnorm_fwd");
 }
 
@@ -748,6 +787,28 @@ int mi355_groupnorm_fwd_cat(const void* x1, int C1, const void* x2, int C2, cons
     if (!x1 || !x2 || !gamma || !beta || !y || !stats || !scratch) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd_cat: null pointer");
     if (C1 < 8 || C2 < 8 || (C1 & 7) || (C2 & 7)) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd_cat: C1 = %d, C2 = %d must be multiples of 8", C1, C2);
     return gn_fwd_launch(x1, x2, C1, gamma, beta, y, stats, scratch, B, HW, C1 + C2, G, eps, silu, stream);
+}
+
+// 1 when mi355_groupnorm_fwd of this geometry runs the statistics pass + the normalising pass (and
+// mi355_groupnorm_fwd_pre can save the first), 0 when one workgroup per (group, sample) does both from registers.
+int mi355_groupnorm_fwd_two_pass(int HW, int C, int G) { return (C % 8 == 0 && G > 0 && C % G == 0 && !gn_small_fwd(HW, C, G)) ? 1 : 0; }
+
+// GroupNorm(+SiLU) forward from statistics that the producer(s) of the input emitted in their epilogues: no pass over x
+// for the sums.  x2 / C1 as in mi355_groupnorm_fwd_cat (x2 NULL: one source).  pre1 [B * tiles1][n1][2] with n1 = C1 / unit
+// (one source: C / unit) runs per row tile and tiles1 row tiles per sample; pre2 likewise for the second source.  Every
+// group must be whole runs: (C / G) % unit == 0 and C1 % unit == 0.  Small maps (one workgroup per group and sample holds
+// the slab in registers) have no use for them: MI355_ERR_UNSUPPORTED, call mi355_groupnorm_fwd.
+int mi355_groupnorm_fwd_pre(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* stats,
+                            const float* pre1, int tiles1, const float* pre2, int tiles2, int unit, int B, int HW, int C, int G,
+                            float eps, int silu, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || !pre1 || (x2 && !pre2)) return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd_pre: null pointer");
+    if (unit < 1 || tiles1 < 1 || (x2 && tiles2 < 1) || C % G || (C / G) % unit || (x2 && (C1 % unit || C1 < 8 || C1 >= C || (C1 & 7) || ((C - C1) & 7))))
+        return mi355_fail(MI355_ERR_ARG, "groupnorm_fwd_pre: groups must be whole runs of %d channels (C=%d C1=%d G=%d)", unit, C, C1, G);
+    if (gn_small_fwd(HW, C, G)) return mi355_fail(MI355_ERR_UNSUPPORTED, "groupnorm_fwd_pre: small map, use mi355_groupnorm_fwd");
+    GnPre q;
+    q.p1 = pre1; q.p2 = pre2; q.t1 = tiles1; q.t2 = x2 ? tiles2 : 0; q.unit = unit;
+    q.n1 = (x2 ? C1 : C) / unit; q.n2 = x2 ? (C - C1) / unit : 0;
+    return gn_fwd_launch(x, x2, x2 ? C1 : 0, gamma, beta, y, stats, nullptr, B, HW, C, G, eps, silu, stream, &q);
 }
 
 // GroupNorm forward for callers that cannot allocate (HIP graph capture, serving loops that forbid hipMalloc): the

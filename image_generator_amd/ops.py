@@ -228,9 +228,46 @@ def gemm_geglu(a, w, bias=None, keep_preact=False):
     return (out, pre) if keep_preact else out
 
 
+# Statistics of a following GroupNorm that the last convolution / product emitted with its output: (sums tensor
+# [B * tiles][channels / unit][2], row tiles per sample, unit), or None.  The module that ran the layer attaches them to
+# the output tensor (`take_gn_pre`), the GroupNorm that reads that tensor skips its statistics pass.
+_LAST_GN_PRE = None
+_GN_PRE_ON = os.environ.get("MI355_NO_GN_PRE") != "1"
+
+
+def take_gn_pre():
+    global _LAST_GN_PRE
+    pre, _LAST_GN_PRE = _LAST_GN_PRE, None
+    return pre
+
+
+def _emit_gn_pre(gstat, rows, rows_per_sample, unit, M, N):
+    """rows: output rows per row tile the launch emitted statistics for (0: none); the buffer was sized for 128-row tiles."""
+    global _LAST_GN_PRE
+    _LAST_GN_PRE = (gstat[:(M // rows) * (N // unit) * 2], rows_per_sample // rows, unit) if rows > 0 else None
+
+
+def gemm_gnstats(a, w, bias, residual, rows_per_sample, unit):
+    """`gemm` with bias / residual whose epilogue also emits the statistics of a following GroupNorm (see
+    mi355_gemm_gnstats_bf16); they are left for `take_gn_pre` when the launch could emit them."""
+    import ctypes
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=BF16, device=a.device)
+    gstat = torch.empty(((M + 127) // 128) * (N // unit) * 2, dtype=F32, device=a.device)
+    rows = ctypes.c_int(0)
+    ws = workspace(a.device)
+    check(lib.mi355_gemm_gnstats_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), M, N, K, out.data_ptr(), N, _ptr(bias),
+                                      _ptr(residual), 0 if residual is None else residual.stride(0), rows_per_sample,
+                                      gstat.data_ptr(), unit, ctypes.byref(rows), ws.data_ptr(), ws.numel(), _stream()), "gemm_gnstats")
+    _emit_gn_pre(gstat, rows.value, rows_per_sample, unit, M, N)
+    return out
+
+
 def conv2d(x, w, cout, ksize, stride=1, ups=False, dil=False, out_hw=None, bias=None, rowbias=None, residual=None,
-           out_fp32=False):
-    """x [B,H,W,C] bf16 NHWC; w physical [Cout][k][k][C] bf16 -> [B,Ho,Wo,Cout]."""
+           out_fp32=False, gn_unit=0):
+    """x [B,H,W,C] bf16 NHWC; w physical [Cout][k][k][C] bf16 -> [B,Ho,Wo,Cout].
+    gn_unit > 0: also emit the statistics of a following GroupNorm (see `take_gn_pre`)."""
     B, H, W, C = x.shape
     assert x.dtype == BF16 and x.is_contiguous()
     pad = ksize // 2
@@ -240,6 +277,16 @@ def conv2d(x, w, cout, ksize, stride=1, ups=False, dil=False, out_hw=None, bias=
     Ho, Wo = out_hw
     out = torch.empty((B, Ho, Wo, cout), dtype=F32 if out_fp32 else BF16, device=x.device)
     ws = workspace(x.device)
+    if gn_unit and _GN_PRE_ON and not out_fp32 and not dil and cout % gn_unit == 0 and (Ho * Wo) % 128 == 0:
+        import ctypes
+        gstat = torch.empty((B * Ho * Wo // 128) * (cout // gn_unit) * 2, dtype=F32, device=x.device)
+        rows = ctypes.c_int(0)
+        check(lib.mi355_conv2d_gnstats_bf16(x.data_ptr(), B, H, W, C, w.data_ptr(), cout, ksize, stride, int(ups), Ho, Wo,
+                                            out.data_ptr(), _ptr(bias), _ptr(rowbias), 0 if rowbias is None else rowbias.stride(0),
+                                            _ptr(residual), gstat.data_ptr(), gn_unit, ctypes.byref(rows), ws.data_ptr(), ws.numel(),
+                                            _stream()), "conv2d_gnstats")
+        _emit_gn_pre(gstat, rows.value, Ho * Wo, gn_unit, B * Ho * Wo, cout)
+        return out
     check(lib.mi355_conv2d_bf16(x.data_ptr(), B, H, W, C, w.data_ptr(), cout, ksize, stride, int(ups), int(dil), Ho, Wo,
                                 out.data_ptr(), int(out_fp32), _ptr(bias), _ptr(rowbias),
                                 0 if rowbias is None else rowbias.stride(0), _ptr(residual), 1.0, ws.data_ptr(),
@@ -589,9 +636,10 @@ class WeightPack:
     bt    : the data gradient reads w16 as stored (gemm_bt / conv2d_dgrad_bt); w16_t is then None and never rebuilt.
     """
     __slots__ = ("w16", "w16_t", "n", "k", "ksize", "cin", "cout", "cin_pad", "cout_pad", "bias_pad", "grad_out",
-                 "bias_grad_out", "on_grad_ready", "bias_parts", "bt")
+                 "bias_grad_out", "on_grad_ready", "bias_parts", "bt", "gn_unit")
 
     def __init__(self):
+        self.gn_unit = 0          # > 0: the layer's output feeds a GroupNorm - emit its statistics in runs of this many channels
         self.bias_parts = 0       # number of trailing bias parameters in LinearFn's `weights` (fused projections)
         self.bt = False
         self.w16 = self.w16_t = None
@@ -610,7 +658,12 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, pack, bias, residual, out_fp32, *weights):
         x2 = x.reshape(-1, x.shape[-1])
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
-        y = gemm(x2, pack.w16.view(pack.n, pack.k), bias=bias, residual=res2, out_fp32=out_fp32)
+        hw = x.shape[1] * x.shape[2] if x.dim() == 4 else 0
+        if pack.gn_unit and _GN_PRE_ON and not out_fp32 and hw % 128 == 0 and hw > 0 and pack.n % pack.gn_unit == 0 and (res2 is None or res2.stride(1) == 1):
+            # a 1x1 convolution on an NHWC map whose output feeds a GroupNorm: statistics out of the epilogue
+            y = gemm_gnstats(x2, pack.w16.view(pack.n, pack.k), bias, res2, hw, pack.gn_unit)
+        else:
+            y = gemm(x2, pack.w16.view(pack.n, pack.k), bias=bias, residual=res2, out_fp32=out_fp32)
         ctx.save_for_backward(x2)
         ctx.pack = pack
         ctx.xshape = x.shape
@@ -810,7 +863,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, rowbias, residual, pack, stride, ups, out_fp32=False):
         kb = bias if (bias is None or pack.bias_pad is None) else pack.bias_pad
         y = conv2d(x, pack.w16, pack.cout_pad, pack.ksize, stride=stride, ups=ups, bias=kb, rowbias=rowbias,
-                   residual=residual, out_fp32=out_fp32)
+                   residual=residual, out_fp32=out_fp32, gn_unit=pack.gn_unit)
         ctx.save_for_backward(x)
         ctx.pack, ctx.stride, ctx.ups = pack, stride, ups
         ctx.flags = (bias is not None, rowbias is not None, residual is not None)
@@ -877,6 +930,46 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, drb, dres, None, None, None, None
 
 
+_GN_TWO_PASS = {}
+
+
+def _gn_pre_usable(hw, C, groups, pre, C1=None, pre2=None):
+    """Whether producer-emitted statistics can stand in for the statistics pass of this GroupNorm: the two-pass geometry,
+    every group whole runs of the emitted unit, and - for a two-source input - statistics of both sources in one unit."""
+    if pre is None or not _GN_PRE_ON:
+        return False
+    key = (hw, C, groups)
+    if key not in _GN_TWO_PASS:
+        _GN_TWO_PASS[key] = bool(lib.mi355_groupnorm_fwd_two_pass(hw, C, groups))
+    unit = pre[2]
+    if not _GN_TWO_PASS[key] or (C // groups) % unit:
+        return False
+    if C1 is not None:
+        return pre2 is not None and pre2[2] == unit and C1 % unit == 0
+    return True
+
+
+def groupnorm_forward(x, x2, gamma, beta, y, stats, groups, eps, silu, pre=None, pre2=None):
+    """GroupNorm(+SiLU) forward of x (or of the channel concatenation [x | x2]) into y / stats: from the producers'
+    statistics when they came with the input(s), else with the statistics pass."""
+    B, H, W, C1 = x.shape
+    C = C1 + (x2.shape[-1] if x2 is not None else 0)
+    if _gn_pre_usable(H * W, C, groups, pre, C1 if x2 is not None else None, pre2):
+        check(lib.mi355_groupnorm_fwd_pre(x.data_ptr(), _ptr(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                          stats.data_ptr(), pre[0].data_ptr(), pre[1], None if x2 is None else pre2[0].data_ptr(),
+                                          0 if x2 is None else pre2[1], pre[2], B, H * W, C, groups, eps, int(silu), _stream()),
+              "groupnorm_fwd_pre")
+        return
+    scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, groups)), dtype=F32, device=x.device)
+    if x2 is None:
+        check(lib.mi355_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                      scratch.data_ptr(), B, H * W, C, groups, eps, int(silu), _stream()), "groupnorm_fwd")
+    else:
+        check(lib.mi355_groupnorm_fwd_cat(x.data_ptr(), C1, x2.data_ptr(), C - C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                          stats.data_ptr(), scratch.data_ptr(), B, H * W, groups, eps, int(silu), _stream()),
+              "groupnorm_fwd_cat")
+
+
 def groupnorm_cat(x1, x2, gamma, beta, groups, eps, silu):
     """GroupNorm(+SiLU) of torch.cat([x1, x2], -1) for NHWC bf16 tensors, without building the concatenation (inference:
     no autograd node)."""
@@ -885,10 +978,7 @@ def groupnorm_cat(x1, x2, gamma, beta, groups, eps, silu):
     assert x2.shape[:3] == x1.shape[:3] and x1.dtype == BF16 and x2.dtype == BF16 and x1.is_contiguous() and x2.is_contiguous()
     y = torch.empty((B, H, W, C1 + C2), dtype=BF16, device=x1.device)
     stats = torch.empty((B, groups, 2), dtype=F32, device=x1.device)
-    scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C1 + C2, groups)), dtype=F32, device=x1.device)
-    check(lib.mi355_groupnorm_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                      stats.data_ptr(), scratch.data_ptr(), B, H * W, groups, eps, int(silu), _stream()),
-          "groupnorm_fwd_cat")
+    groupnorm_forward(x1, x2, gamma, beta, y, stats, groups, eps, silu, getattr(x1, "_gn_pre", None), getattr(x2, "_gn_pre", None))
     return y
 
 
@@ -900,16 +990,13 @@ class CatNormShortcutFn(torch.autograd.Function):
     weight needs its preassigned gradient buffer (`cat_train_ready`)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, gamma, beta, groups, eps, silu, gdst, pack, sc_bias, sc_weight):
+    def forward(ctx, x1, x2, gamma, beta, groups, eps, silu, gdst, pack, sc_bias, sc_weight, pre1=None, pre2=None):
         B, H, W, C1 = x1.shape
         C2 = x2.shape[-1]
         C = C1 + C2
         y = torch.empty((B, H, W, C), dtype=BF16, device=x1.device)
         stats = torch.empty((B, groups, 2), dtype=F32, device=x1.device)
-        scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, groups)), dtype=F32, device=x1.device)
-        check(lib.mi355_groupnorm_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                          stats.data_ptr(), scratch.data_ptr(), B, H * W, groups, eps, int(silu), _stream()),
-              "groupnorm_fwd_cat")
+        groupnorm_forward(x1, x2, gamma, beta, y, stats, groups, eps, silu, pre1, pre2)
         w = pack.w16.view(pack.n, C)
         if C1 % 64 == 0 and C2 % 64 == 0 and pack.n % 160 == 0:
             res = gemm_cat(x1.view(-1, C1), x2.view(-1, C2), w, bias=sc_bias)
@@ -971,7 +1058,7 @@ class CatNormShortcutFn(torch.autograd.Function):
         elif want_db:
             dbias = colsum(dr2)[0]
         gg, gb = (None, None) if (direct or frozen) else (dg, db)
-        return dx1, dx2, gg, gb, None, None, None, None, None, dbias, dw
+        return dx1, dx2, gg, gb, None, None, None, None, None, dbias, dw, None, None
 
 
 def cat_train_ready(pack, weight):
@@ -986,16 +1073,15 @@ _DX_COLSUMS = {}
 
 class GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu, gdst=None, passthrough=False, colsum=False):
+    def forward(ctx, x, gamma, beta, groups, eps, silu, gdst=None, passthrough=False, colsum=False, pre=None):
         """gdst: optional (dgamma, dbeta) fp32 views the parameter gradients are written into directly.
         passthrough: also return x itself, for the branch that reads x beside the norm (residual / shortcut);
-        backward then adds that branch's gradient inside the normalisation kernel instead of a separate add."""
+        backward then adds that branch's gradient inside the normalisation kernel instead of a separate add.
+        pre: the statistics x's producer emitted with it (`take_gn_pre`), if any."""
         B, H, W, C = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((B, groups, 2), dtype=F32, device=x.device)
-        scratch = torch.empty(int(lib.mi355_groupnorm_scratch_floats(B, H * W, C, groups)), dtype=F32, device=x.device)
-        check(lib.mi355_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
-                                      scratch.data_ptr(), B, H * W, C, groups, eps, int(silu), _stream()), "groupnorm_fwd")
+        groupnorm_forward(x, None, gamma, beta, y, stats, groups, eps, silu, pre)
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.groups, ctx.silu, ctx.gdst = groups, silu, gdst
         # colsum: x is the output of a convolution with a per-sample bias; backward leaves that bias's gradient (the
@@ -1037,8 +1123,8 @@ class GroupNormFn(torch.autograd.Function):
             strips = nsc // (B * (2 * G + 2 * C))
             _REDUCE_QUEUE.push(scratch.data_ptr() + 4 * B * strips * G * 2, db, dg, B * strips, 2 * C, C, scratch)
         if direct or frozen:
-            return dx, None, None, None, None, None, None, None, None
-        return dx, dg, db, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -125,8 +125,14 @@ class HipConv2d(nn.Module):
 
     def forward(self, x, rowbias=None, residual=None, ups=False, out_fp32=False):
         if self.kernel_size == 1 and self.stride == 1 and not self.padded:
-            return LinearFn.apply(x, self.pack, self.bias, residual, out_fp32, self.weight)
-        return ConvFn.apply(x, self.weight, self.bias, rowbias, residual, self.pack, self.stride, ups, out_fp32)
+            y = LinearFn.apply(x, self.pack, self.bias, residual, out_fp32, self.weight)
+        else:
+            y = ConvFn.apply(x, self.weight, self.bias, rowbias, residual, self.pack, self.stride, ups, out_fp32)
+        if self.pack.gn_unit:           # the statistics of the GroupNorm(s) that read this output came out of its epilogue
+            pre = ops.take_gn_pre()
+            if pre is not None:
+                y._gn_pre = pre
+        return y
 
 
 class HipGroupNorm(nn.Module):
@@ -140,9 +146,10 @@ class HipGroupNorm(nn.Module):
     def forward(self, x, silu, passthrough=False, colsum=False):
         """passthrough: returns (y, x') where x' is x for the branch that bypasses the norm (see GroupNormFn).
         colsum: x comes from a convolution with a per-sample bias, whose gradient the backward kernel then also produces."""
+        pre = getattr(x, "_gn_pre", None)
         if passthrough and not (torch.is_grad_enabled() and x.requires_grad):
-            return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst), x
-        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst, passthrough, colsum)
+            return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst, False, False, pre), x
+        return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self.grad_dst, passthrough, colsum, pre)
 
 
 class HipLayerNorm(nn.Module):
@@ -214,7 +221,7 @@ class ResnetBlock(nn.Module):
         """The same with autograd: the two input gradients leave as separate tensors (ops.CatNormShortcutFn)."""
         n1, sc = self.norm1, self.conv_shortcut
         h, res = CatNormShortcutFn.apply(x1, x2, n1.weight, n1.bias, n1.num_groups, n1.eps, True, n1.grad_dst, sc.pack,
-                                         sc.bias, sc.weight)
+                                         sc.bias, sc.weight, getattr(x1, "_gn_pre", None), getattr(x2, "_gn_pre", None))
         rb = self._tproj if self._tproj is not None else self.time_emb_proj(temb_act, out_fp32=True)
         h = self.conv1(h, rowbias=rb)
         h = self.norm2(h, silu=True, colsum=_COLSUM_FUSION and rb.requires_grad)
@@ -560,6 +567,19 @@ class UNet2DConditionModel(nn.Module):
             self.up_blocks.append(UpBlock(cfg, cin, cout, cprev, rev_attn[i], i != len(ch) - 1))
         self.conv_norm_out = HipGroupNorm(cfg.norm_num_groups, ch[0], cfg.norm_eps)
         self.conv_out = HipConv2d(ch[0], cfg.out_channels, 3)
+        # every layer whose output is read by a GroupNorm emits that norm's statistics from its own epilogue, in runs of
+        # channels that divide every group that can contain them (the up path concatenates maps of different widths:
+        # groups of 30 or 60 channels over sources whose own groups are 10, 20 or 40 wide)
+        unit = 10 if all(c % 320 == 0 for c in ch) and cfg.norm_num_groups == 32 else (8 if all((c // cfg.norm_num_groups) % 8 == 0 for c in ch) else 0)
+        if unit and os.environ.get("MI355_NO_GN_PRE") != "1":
+            for m in self.modules():
+                if isinstance(m, ResnetBlock):
+                    m.conv1.pack.gn_unit = m.conv2.pack.gn_unit = unit
+                elif isinstance(m, Transformer2D):
+                    m.proj_out.pack.gn_unit = unit
+                elif isinstance(m, (Downsample, Upsample)):
+                    m.conv.pack.gn_unit = unit
+            self.conv_in.pack.gn_unit = unit
         # flat-buffer state (built lazily on the device the parameters live on)
         self._flat = None
         self._flat16 = None

@@ -111,6 +111,33 @@ int mi355_gemm_bt_bf16(const void* A, int lda, const void* W, int ldw, int M, in
 int mi355_conv2d_dgrad_bt_bf16(const void* dy, int B, int H, int W, int Cout, const void* w, int Cin, int ksize, int dil,
                                int Ho, int Wo, void* dx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* GroupNorm statistics out of the producing epilogue (the residual blocks' and transformer wrappers' GroupNorms of the
+ * third-party denoiser called at image_generator.py:93-95 / :124 read what a convolution or a 1x1 projection has just
+ * written): the convolution / product below also emits, per row tile and run of `unit` (8 or 10) adjacent output
+ * channels, the sum and the sum of squares of the bf16 values it stores - gstat [M / rows][N / unit][2], rows = *rows_out
+ * (128 or 256 output rows, all of one sample) - and mi355_groupnorm_fwd_pre normalises from those sums without a
+ * statistics pass over its input.  *rows_out = 0: this launch could not emit them (split contraction, a row tile that
+ * would span two samples, channel counts outside the 160-column tiles): it ran as the plain product, gstat is untouched,
+ * the caller takes mi355_groupnorm_fwd.  gstat must hold (M / 128) * (N / unit) * 2 floats.
+ *   mi355_conv2d_gnstats_bf16: as mi355_conv2d_bf16 (bf16 output, alpha 1, no dilation).
+ *   mi355_gemm_gnstats_bf16:   out = A Bw^T + bias + residual; rows_per_sample = rows of A per sample (H * W).
+ *   mi355_groupnorm_fwd_pre:   x2 / C1 as in mi355_groupnorm_fwd_cat (x2 NULL: one source, C1 ignored); pre1 / tiles1 the
+ *                              first (only) source's sums and row tiles per sample, pre2 / tiles2 the second's; every
+ *                              group must be whole runs ((C / G) % unit == 0, C1 % unit == 0). */
+int mi355_conv2d_gnstats_bf16(const void* x, int B, int H, int W, int C, const void* w, int Cout, int ksize, int stride,
+                              int ups, int Ho, int Wo, void* out, const float* bias, const float* rowbias, int ld_rowbias,
+                              const void* residual, float* gstat, int unit, int* rows_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int mi355_gemm_gnstats_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
+                            const float* bias, const void* residual, int ldr, int rows_per_sample, float* gstat, int unit,
+                            int* rows_out, void* workspace, size_t workspace_bytes, void* stream);
+int mi355_groupnorm_fwd_pre(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* stats,
+                            const float* pre1, int tiles1, const float* pre2, int tiles2, int unit, int B, int HW, int C, int G,
+                            float eps, int silu, void* stream);
+/* 1 when mi355_groupnorm_fwd of this geometry takes two passes (statistics, then normalisation) and
+ * mi355_groupnorm_fwd_pre saves the first; 0 for the small maps that one workgroup per (group, sample) holds in registers. */
+int mi355_groupnorm_fwd_two_pass(int HW, int C, int G);
+
 /* LayerNorm folded into the two products around it, for the no-gradient denoiser call of the sampling loop
  * (image_generator.py:92-95: the transformer blocks' `norm1/2/3` followed by `attn1.to_q/k/v`, `attn2.to_q`, `ff.net.0.proj`
  * in the third-party block): the normalised activations are never written or re-read.

@@ -1220,3 +1220,68 @@ def test_layernorm_folded_into_the_products_around_it(case):
         z_f = y_f[:, :F] * torch.nn.functional.gelu(y_f[:, F:])
         z_k = ops.gemm_geglu(ops.layernorm_bf16(x, gamma, beta, 1e-5), w1.to(BF), b1)
         assert z.shape == (M, F) and rel_l2(z, z_k) <= 1.5e-2 and rel_l2(z, z_f) <= 2e-2, (rel_l2(z, z_k), rel_l2(z, z_f))
+
+
+@pytest.mark.parametrize("case", [("conv", 16, 32, 32, 320, 320, "dma"), ("conv", 8, 64, 64, 320, 320, "pp/wide"), ("conv_res", 32, 32, 32, 640, 320, "rowbias+res"),
+                                  ("conv_ups", 32, 16, 16, 320, 320, "ups"), ("dense", 4, 32, 32, 320, 320, "1x1+res"), ("dense", 8, 64, 64, 640, 640, "1x1 wide"),
+                                  ("split", 2, 16, 16, 1280, 1280, "split-K: none"), ("conv8", 32, 32, 32, 128, 160, "unit 8")])
+def test_groupnorm_statistics_out_of_the_producing_epilogue(case):
+    """mi355_conv2d_gnstats_bf16 / mi355_gemm_gnstats_bf16 -> mi355_groupnorm_fwd_pre against the plain product followed by
+    mi355_groupnorm_fwd.  (1) the emitting launch stores the plain launch's bits; (2) its sums are the sums of those bits
+    per (row tile, run of channels); (3) the GroupNorm fed with them equals the two-pass GroupNorm up to the order of the
+    fp32 additions (|diff| <= 1 bf16 ulp on almost every element); (4) a launch that cannot emit (split contraction) says so
+    and the caller's fallback is the plain path; (5) two sources with different tilings feed one concatenated norm."""
+    from image_generator_amd import ops
+    d = dev()
+    kind, B, H, W, Cin, Cout, _ = case
+    unit = 8 if kind == "conv8" else 10
+    G = 32 if unit == 10 else 4
+    g = torch.Generator().manual_seed(B * H + Cin + Cout)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.5 + 0.2).to(BF).to(d)
+    bias = torch.randn(Cout, generator=g).to(d)
+    ups = kind == "conv_ups"
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    res = (torch.randn(B, Ho, Wo, Cout, generator=g)).to(BF).to(d) if kind in ("conv_res", "dense") else None
+    rb = torch.randn(B, Cout, generator=g).to(d) if kind == "conv_res" else None
+    if kind == "dense":
+        w = (torch.randn(Cout, Cin, generator=g) * Cin ** -0.5).to(BF).to(d)
+        plain = ops.gemm(x.view(-1, Cin), w, bias=bias, residual=res.view(-1, Cout)).view(B, H, W, Cout)
+        out = ops.gemm_gnstats(x.view(-1, Cin), w, bias, res.view(-1, Cout), H * W, unit).view(B, H, W, Cout)
+    else:
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (9 * Cin) ** -0.5).to(BF).to(d)
+        plain = ops.conv2d(x, w, Cout, 3, ups=ups, bias=bias, rowbias=rb, residual=res)
+        out = ops.conv2d(x, w, Cout, 3, ups=ups, bias=bias, rowbias=rb, residual=res, gn_unit=unit)
+    pre = ops.take_gn_pre()
+    assert torch.equal(out, plain)
+    if kind == "split":
+        assert pre is None                      # (4)
+        return
+    assert pre is not None, "the launch should have emitted statistics"
+    gstat, tiles, u = pre
+    rows = Ho * Wo // tiles
+    assert u == unit and rows in (128, 256)
+    of = out.float().view(B, tiles, rows, Cout // unit, unit)
+    got = gstat.view(B, tiles, Cout // unit, 2)
+    assert torch.allclose(got[..., 0], of.sum((2, 4)), rtol=1e-4, atol=5e-2)
+    assert torch.allclose(got[..., 1], (of * of).sum((2, 4)), rtol=1e-4, atol=5e-2)
+    gamma, beta = torch.randn(Cout, generator=g).to(d), torch.randn(Cout, generator=g).to(d)
+    y0, y1 = torch.empty_like(out), torch.empty_like(out)
+    s0, s1 = torch.empty(B, G, 2, device=d), torch.empty(B, G, 2, device=d)
+    ops.groupnorm_forward(out, None, gamma, beta, y0, s0, G, 1e-5, True)
+    ops.groupnorm_forward(out, None, gamma, beta, y1, s1, G, 1e-5, True, pre)
+    assert torch.allclose(s0, s1, rtol=2e-5, atol=2e-5)
+    diff = (y0.float() - y1.float()).abs()
+    assert float((diff > 2 ** -7 * y0.float().abs() + 1e-6).float().mean()) < 1e-3 and float(diff.max()) <= 0.1
+    if kind == "dense" and Cout == 640:         # (5): [this 640-wide map | a 320-wide one] under one 32-group norm (30 channels per group)
+        x2 = (torch.randn(B, H, W, 320, generator=g)).to(BF).to(d)
+        w2 = (torch.randn(320, 3, 3, 320, generator=g) * 2880 ** -0.5).to(BF).to(d)
+        o2 = ops.conv2d(x2, w2, 320, 3, bias=None, gn_unit=unit)
+        pre2 = ops.take_gn_pre()
+        assert pre2 is not None
+        gc, bc = torch.randn(960, generator=g).to(d), torch.randn(960, generator=g).to(d)
+        yc0, yc1 = torch.empty(B, H, W, 960, dtype=BF, device=d), torch.empty(B, H, W, 960, dtype=BF, device=d)
+        sc0, sc1 = torch.empty(B, 32, 2, device=d), torch.empty(B, 32, 2, device=d)
+        ops.groupnorm_forward(out, o2, gc, bc, yc0, sc0, 32, 1e-5, True)
+        ops.groupnorm_forward(out, o2, gc, bc, yc1, sc1, 32, 1e-5, True, pre, pre2)
+        assert torch.allclose(sc0, sc1, rtol=2e-5, atol=2e-5)
+        assert float((yc0.float() - yc1.float()).abs().max()) <= 0.1
