@@ -18,11 +18,16 @@ def family(name):
 f = glob.glob(f"{sys.argv[1]}/**/*counter_collection.csv", recursive=True)[0]
 busy, act, cnt = collections.Counter(), collections.Counter(), collections.Counter()
 per_kernel = collections.defaultdict(lambda: [0.0, 0.0, 0])
-steps = 0
-for r in csv.DictReader(open(f)):
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+# whole steps only: the launches between the first and the last optimizer launch of the pass
+marks = sorted({int(r["Dispatch_Id"]) for r in rows if "adamw_kernel" in r["Kernel_Name"]})
+if len(marks) < 2:
+    raise SystemExit("fewer than two optimizer launches in the pass")
+steps = len(marks) - 1
+for r in rows:
+    if not (marks[0] < int(r["Dispatch_Id"]) <= marks[-1]):
+        continue
     name, c, v = r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
-    if "adamw_kernel" in name and c == "GRBM_GUI_ACTIVE":
-        steps += 1
     fam = family(name)
     if fam is None:
         continue

@@ -18,17 +18,21 @@ def family(name):
 
 
 def load(d, counter):
+    """Per-family totals over the launches BETWEEN the run's first and last optimizer launch (whole steps only: model
+    initialisation, the first step's head and whatever follows the last optimizer launch - bench.py's own yardstick
+    kernels - stay outside), and the number of steps that window holds."""
     f = glob.glob(f"{d}/{counter}/**/*counter_collection.csv", recursive=True)[0]
-    tot, cnt, steps = collections.Counter(), collections.Counter(), 0
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
-            continue
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    marks = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
+    if len(marks) < 2:
+        raise SystemExit(f"{counter}: fewer than two optimizer launches in the pass")
+    tot, cnt = collections.Counter(), collections.Counter()
+    for r in rows[marks[0] + 1:marks[-1] + 1]:
         fam = family(r["Kernel_Name"])
         tot[fam] += float(r["Counter_Value"]) * 1024.0
         cnt[fam] += 1
-        if "adamw_kernel" in r["Kernel_Name"]:
-            steps += 1
-    return tot, cnt, steps
+    return tot, cnt, len(marks) - 1
 
 
 d = sys.argv[1]
@@ -38,7 +42,8 @@ from bench import source_fingerprint          # noqa: E402  (bench.py only reads
 
 out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --no-graph --steps 2 --warmup 1 --prof-steps 0 --no-cpu-baseline --no-extra",
        "source_fingerprint": source_fingerprint(),
-       "steps_in_run": fs, "note": "bytes at the L2's memory side (Infinity-Cache hits included); fetch = 2 x FETCH_SIZE (gfx950 wide-read correction)",
+       "steps_in_run": fs, "window": "launches between the first and the last optimizer launch of the pass (whole steps; no initialisation, no yardstick kernels)",
+       "note": "bytes at the L2's memory side (Infinity-Cache hits included); fetch = 2 x FETCH_SIZE (gfx950 wide-read correction)",
        "families": {}}
 for fam in [f for f, _ in FAMS] + ["other"]:
     if fc[fam] == 0:
