@@ -86,12 +86,6 @@ struct GemmArgs {
     // GroupNorm statistics out of the producing epilogue (AMODE_DENSE_LN / AMODE_CONV_GS): gstat_out [tiles_m][N / gs_unit][2]
     // receives, per row tile and per run of gs_unit (8 or 10) adjacent output channels, the sum and the sum of squares of
     // the bf16 values this launch stores.  A row tile must lie inside one sample; the consumer's groups are whole runs.
-    // convolutions: order of the contraction.  0: tap-major (all channels of tap 0, then tap 1, ...); 1: a 64-channel
-    // slice at a time through all of its taps.  Tap-major re-reads a pixel's neighbourhood a whole pass over the
-    // channels apart: at 640 channels and more the rows a tile needs no longer stay in the XCD's L2 between two taps
-    // and every tap fetches them again (measured 8.5 x the operand bytes at 640 -> 320 channels on a 32 x 32 map,
-    // 1.6 x at 320 -> 320); slice-major keeps (128 + halo) pixels x 64 channels live per workgroup.
-    int tap_inner;
     float* gstat_out;
     int gs_unit;
     float* rowstat_out;
@@ -222,6 +216,23 @@ __device__ __forceinline__ void ln_fold_column(const GemmArgs& p, int n0, int ti
     const int n = p.geglu ? (tid < BN / 2 ? f0 + tid : F + f0 + tid - BN / 2) : n0 + tid;
     const bool ok = p.geglu ? (tid < BN / 2 ? f0 + tid < F : f0 + tid - BN / 2 < F) : n < p.N;
     if (ok) { if (p.ln_part) ln_c = p.ln_cs[n]; if (p.bias) ln_b = p.bias[n]; }
+}
+
+// Convolutions contract one 64-channel slice through all of its taps at a time: k-tile kt of a 3x3 layer is (slice
+// kt / 9, tap kt % 9) - computed from kt with a multiply and a shift, no state carried from tile to tile (counters
+// advanced inside the request lambdas ended up in scratch memory: +1.9 ms per train step).  1x1: slice kt, tap 0.
+// Tap-major order (all channels of tap 0, then tap 1, ...) re-reads a pixel's neighbourhood a whole pass over the
+// channels apart: at 640 channels and more the rows a tile needs no longer stay in the XCD's L2 between two taps
+// (measured 8.5 x the operand bytes fetched at 640 -> 320 channels on a 32 x 32 map, 1.6 x in this order).
+__device__ __forceinline__ void conv_ktile(int kt, int ksize, int& slice, int& ky, int& kx) {
+    if (ksize == 3) {
+        slice = (kt * 7282) >> 16;              // kt / 9 for kt < 16384 (K = 9 * 64 * 16384 channels: far beyond any layer)
+        const int tap = kt - slice * 9;
+        ky = (tap * 11) >> 5;                   // tap / 3 for tap < 9
+        kx = tap - ky * 3;
+    } else {
+        slice = kt; ky = 0; kx = 0;
+    }
 }
 
 // The same in two halves for the kernels with LDS to spare (one request burst at kernel start, no register and no
@@ -836,7 +847,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
     // requested in increasing order: the tap and the channel offset advance by increments, no division per tile.
     const bool conv_affine = !amode_dense(AMODE) && !p.g.ups && !p.g.dil;
     int a_base[A_P], a_mask[A_P];
-    int cur_c = 0, cur_ky = 0, cur_kx = 0;
     if constexpr (!amode_dense(AMODE)) {
 #pragma unroll
         for (int j = 0; j < A_P; ++j) {
@@ -852,26 +862,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
             }
             a_mask[j] = mask;
         }
-        if (p.tap_inner && p.g.ksize == 3) {        // k-tile kt = (64-channel slice kt / 9, tap kt % 9)
-            const int sl = kt_begin / 9, tap = kt_begin - sl * 9;
-            cur_c = sl * BK; cur_ky = tap / 3; cur_kx = tap - cur_ky * 3;
-        } else {
-            const int kk = kt_begin * BK;
-            const int tap = kk / p.g.C;
-            cur_c = kk - tap * p.g.C;
-            if (p.g.ksize == 3) { cur_ky = tap / 3; cur_kx = tap - cur_ky * 3; }
-        }
     }
 
     auto issue = [&](int kt, int stage) {
         char* As = smem + stage * STAGE;
         char* Bs = As + BM * 128;
         int soffb = kt * (BK * 2);
+        int cur_c = 0, cur_ky = 0, cur_kx = 0;
+        if constexpr (!amode_dense(AMODE)) {
+            int slice;
+            conv_ktile(kt, p.g.ksize, slice, cur_ky, cur_kx);
+            cur_c = slice * BK;
+            soffb = ((cur_ky * 3 + cur_kx) * p.g.C + cur_c) * 2;                       // weight row: [tap][channel]
+        }
         if constexpr (BT) {
             if constexpr (amode_dense(AMODE)) soffb = kt * BK * p.bt_ld * 2;
             else soffb = (cur_c * p.bt_ld + (p.g.ksize == 3 ? 8 - (cur_ky * 3 + cur_kx) : 0) * p.N) * 2;
-        } else if constexpr (!amode_dense(AMODE)) {
-            if (p.tap_inner) soffb = ((cur_ky * 3 + cur_kx) * p.g.C + cur_c) * 2;      // weight row: [tap][channel]
         }
         if constexpr (AMODE == AMODE_DENSE_CAT) {
             if (kt * BK < p.K1) {            // (uniform) the k-tile lies in the first source ...
@@ -912,15 +918,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_dma_kernel(cons
                     voff = ok ? ((a_voff[j] + sy * p.g.W + sx) * p.g.C + kc * 8) * 2 : OOB_OFF;
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(As + (wave + NW * j) * 1024), 16, voff, soff, 0, 0);
-            }
-            if (p.tap_inner && p.g.ksize == 3) {
-                if (++cur_kx == 3) { cur_kx = 0; if (++cur_ky == 3) { cur_ky = 0; cur_c += BK; } }
-            } else {
-                cur_c += BK;
-                if (cur_c >= p.g.C) {
-                    cur_c = 0;
-                    if (++cur_kx == 3) { cur_kx = 0; ++cur_ky; }
-                }
             }
         }
 #pragma unroll
@@ -1108,7 +1105,6 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
     // (tiles are requested in increasing order) - see gemm_dma_kernel
     const bool conv_affine = !amode_dense(AMODE) && !p.g.ups && !p.g.dil;
     int a_base[NP], a_mask[NP];
-    int cur_c = 0, cur_ky = 0, cur_kx = 0;
     if constexpr (!amode_dense(AMODE)) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -1126,16 +1122,17 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
         }
     }
 
-    // tap_inner: 64-channel slice, tap, 32-channel half - the order of the 64-deep kernels, k-step by k-step
-    int cur_half = 0;
+    // convolutions: 32-deep slab kt = (64-channel slice, tap, 32-channel half) - the order of the 64-deep kernels, k-step by k-step
     auto issue = [&](int kt, int stage) {
         char* base = smem + stage * STAGE;
         int soffb = kt * (BK * 2);
         int soffa = soffb, ky = 0, kx = 0;
         if constexpr (!amode_dense(AMODE)) {
-            soffa = (cur_c + cur_half) * 2;
-            ky = cur_ky; kx = cur_kx;
-            if (p.tap_inner) soffb = ((ky * 3 + kx) * p.g.C + cur_c + cur_half) * 2;
+            int slice;
+            conv_ktile(kt >> 1, p.g.ksize, slice, ky, kx);
+            const int c = slice * (2 * BK) + (kt & 1) * BK;
+            soffa = c * 2;
+            soffb = ((ky * 3 + kx) * p.g.C + c) * 2;
         }
         const int tap_off = (ky * p.g.W + kx) * p.g.C * 2, tap_bit = ky * 3 + kx;
 #pragma unroll
@@ -1163,18 +1160,6 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs p, uns
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + pc * 1024), 16, v, soffa, 0, 0);
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base + pc * 1024), 16, voff[q], soffb, 0, 0);
-            }
-        }
-        if constexpr (!amode_dense(AMODE)) {
-            if (p.tap_inner && p.g.ksize == 3) {
-                cur_half ^= BK;
-                if (cur_half == 0 && ++cur_kx == 3) { cur_kx = 0; if (++cur_ky == 3) { cur_ky = 0; cur_c += 2 * BK; } }
-            } else {
-                cur_c += BK;
-                if (cur_c >= p.g.C) {
-                    cur_c = 0;
-                    if (++cur_kx == 3) { cur_kx = 0; ++cur_ky; }
-                }
             }
         }
     };
@@ -1318,17 +1303,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsig
             }
         }
     }
-    int cur_c = 0, cur_ky = 0, cur_kx = 0;                   // of the next slab to be requested (conv only)
-    // tap_inner: 64-channel slice, tap, 32-channel half (the order of the 64-deep kernels); a slab's B pieces are
-    // requested right after its A pieces (no other slab's A in between), so issue_a leaves their offset in b_soff
-    int cur_half = 0, b_soff = 0;
+    // convolutions: 32-deep slab = (64-channel slice, tap, 32-channel half), the order of the 64-deep kernels
     auto issue_a = [&](int slab) {
         char* base = smem + (slab & 3) * STAGE;
         int soffa = slab * (BK * 2), ky = 0, kx = 0;
         if constexpr (!amode_dense(AMODE)) {
-            soffa = (cur_c + cur_half) * 2;
-            ky = cur_ky; kx = cur_kx;
-            b_soff = p.tap_inner ? ((ky * 3 + kx) * p.g.C + cur_c + cur_half) * 2 : slab * (BK * 2);
+            int slice;
+            conv_ktile(slab >> 1, p.g.ksize, slice, ky, kx);
+            soffa = (slice * (2 * BK) + (slab & 1) * BK) * 2;
         }
         const int tap_off = (ky * p.g.W + kx) * p.g.C * 2, tap_bit = ky * 3 + kx;
 #pragma unroll
@@ -1352,22 +1334,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmArgs p, unsig
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + (wave + NW * q) * 1024), 16, v, soffa, 0, 0);
         }
-        if constexpr (!amode_dense(AMODE)) {
-            if (p.tap_inner && p.g.ksize == 3) {
-                cur_half ^= BK;
-                if (cur_half == 0 && ++cur_kx == 3) { cur_kx = 0; if (++cur_ky == 3) { cur_ky = 0; cur_c += 2 * BK; } }
-            } else {
-                cur_c += BK;
-                if (cur_c >= p.g.C) {
-                    cur_c = 0;
-                    if (++cur_kx == 3) { cur_kx = 0; ++cur_ky; }
-                }
-            }
-        }
     };
     auto issue_b = [&](int slab) {
         char* base = smem + (slab & 3) * STAGE + A_PIECES * 1024;
-        const int soffb = amode_dense(AMODE) ? slab * (BK * 2) : b_soff;
+        int soffb = slab * (BK * 2);
+        if constexpr (!amode_dense(AMODE)) {
+            int slice, ky, kx;
+            conv_ktile(slab >> 1, p.g.ksize, slice, ky, kx);
+            soffb = ((ky * 3 + kx) * p.g.C + slice * (2 * BK) + (slab & 1) * BK) * 2;
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base + wave * 1024), 16, b_voff[0], soffb, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base + (wave + NW) * 1024), 16, b_voff[1], soffb, 0, 0);
         if (wave < 4)
@@ -1694,8 +1669,6 @@ static int run_gemm(GemmArgs a, int amode, void* ws, size_t ws_bytes, hipStream_
     if (a.rowbias && a.rowbias_div <= 0) return mi355_fail(MI355_ERR_ARG, "gemm: rowbias_div must be positive");
     if (((uintptr_t)a.bias & 15) || ((uintptr_t)a.rowbias & 15) || (a.rowbias && (a.ld_rowbias & 3)))
         return mi355_fail(MI355_ERR_ARG, "gemm: bias / rowbias must be 16-byte aligned (rowbias stride a multiple of 4 floats)");
-    static const int tap_inner = getenv("MI355_CONV_TAP_INNER") ? atoi(getenv("MI355_CONV_TAP_INNER")) : 1;
-    a.tap_inner = (!amode_dense(amode) && amode != AMODE_CONV_GENERIC && a.g.ksize == 3 && a.g.C % 64 == 0) ? tap_inner : 0;
     a.rowbias_shift = -1;
     if (a.rowbias_div > 0 && !(a.rowbias_div & (a.rowbias_div - 1))) {
         a.rowbias_shift = 0;
