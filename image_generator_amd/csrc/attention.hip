@@ -120,9 +120,17 @@ struct TileFetch {
 // =============================================================================================
 // ONES (needs D < 32 * NO): the softmax denominators are accumulated by the P V product itself, through a column of
 // ones in the V tile's padding - 32 fewer additions per lane and key tile in a loop that is VALU-bound at small D.
-template <int ND, int NO, bool ONES, bool DROP = false>
+// PS (with ONES, without DROP): the caller folded scale * log2(e) into q, so a score leaves the matrix pipe as the exponent
+// of its probability, and the key loop takes NO running maximum: p = exp2(s) against the fixed reference 0.  Floating
+// point does not care about the common factor as long as nothing leaves the normal range, and bf16 probabilities have
+// fp32's exponent range; a row whose sum (read from the ones column after the loop) is not within 2^-100 .. 2^100 - scores
+// beyond about +-100 in log2 units, or a NaN - sends its workgroup through the loop again with the running maximum.  Per
+// key tile and lane that is 32 v_exp + 16 conversions instead of 32 v_fma + 16 v_max3 + 32 v_exp + 16 conversions and the
+// rescaling test: -13 % at 4 096 tokens, -15 % at 1 024 (d = 40).
+template <int ND, int NO, bool ONES, bool DROP = false, bool PS = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     static_assert(!(ONES && DROP), "the ones column would sum the dropped probabilities");
+    static_assert(!PS || (ONES && !DROP), "the prescaled form reads its row sums from the ones column");
     constexpr int DP = 16 * ND;
     constexpr int KLD = DP * 2 + 16;
     constexpr int VLD = tr_ld(NO);
@@ -172,6 +180,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     TileFetch<NCV> vfetch;
     kfetch.template init<false>(Kb, p.ldk, Nk, p.D, 64, DP / 8);
     vfetch.template init<ONES>(Vb, p.ldv, Nk, p.D, 64, NO * 4);
+    const float sl2 = PS ? 1.f : p.scale_log2;
+    // FAST: no running maximum (PS only, see above)
+    auto run_tiles = [&](auto fast_c) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_c)::value;
     kfetch.template load<false>(kreg, 0);
     vfetch.template load<ONES>(vreg, 0);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -233,7 +245,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
                 }
         }
-        float mx = -INFINITY;
         if (k0 + 64 > Nk) {            // only the last key tile can hold padded keys (wave-uniform branch)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -243,11 +254,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                     if (key >= Nk) s[kb][r] = -INFINITY;
                 }
         }
+        if constexpr (FAST) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = EXP2(s[kb][r]);
+        } else {
+        float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;      // scale > 0: max commutes with the scaling
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2;      // scale > 0: max commutes with the scaling
         const float m_new = fmaxf(m, mx);
         const float alpha = EXP2(m - m_new);
         float sum = 0.f;
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = EXP2(fmaf(s[kb][r], p.scale_log2, -m_new));
+                const float e = EXP2(fmaf(s[kb][r], sl2, -m_new));
                 s[kb][r] = e;
                 if (!ONES) sum += e;
                 if (DROP) {     // the denominator sums every probability, the product with V only the kept ones
@@ -275,6 +293,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
         }
         m = m_new;
+        }
 
         bf16x8 pf[2][2];
 #pragma unroll
@@ -306,11 +325,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         }
     }
 
-    if (ONES) {
-        // the ones column is row D % 32 of the last 32-row block of O^T: register (D % 32) / 2 of the lanes with hh = 0
+    };
+    // the ones column is row D % 32 of the last 32-row block of O^T: register (D % 32) / 2 of the lanes with hh = 0
+    auto ones_sum = [&]() {
         const int c = p.D & 31;
         const float lsum = c == 8 ? o[NO - 1][4] : c == 16 ? o[NO - 1][8] : o[NO - 1][12];
-        l = __shfl(lsum, l31, 64);
+        return __shfl(lsum, l31, 64);
+    };
+    if constexpr (PS) {
+        m = 0.f;
+        run_tiles(std::true_type{});
+        l = ones_sum();
+        if (__syncthreads_or(!(l > 0x1p-100f && l < 0x1p100f))) {      // (uniform over the workgroup: the loop has barriers)
+#pragma unroll
+            for (int i = 0; i < NO; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+            m = -INFINITY;
+            run_tiles(std::false_type{});
+            l = ones_sum();
+        }
+    } else {
+        run_tiles(std::false_type{});
+        if (ONES) l = ones_sum();
     }
     if (q_ok) {
         const float inv = 1.f / l;
@@ -631,6 +668,18 @@ static int launch_fwd(const AttnArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((attn_fwd_kernel<ND, NO, false>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
     return mi355_check_launch("attn_fwd");
 }
+// q already carries scale * log2(e) (a.scale_log2 == 1): heads with a spare padding column take the loop without a running
+// maximum, the others the plain kernel.
+template <int ND, int NO>
+static int launch_fwd_ps(const AttnArgs& a, hipStream_t s) {
+    if constexpr (NO <= 2) {      // (d = 80 in three 32-wide blocks: measured, +-0 in the sampling step)
+        if (a.D < 32 * NO && mi355_g_tune[0] != 1) {      // mi355_tune_set(0, 1): plain kernel (A/B inside one process)
+            hipLaunchKernelGGL((attn_fwd_kernel<ND, NO, true, false, true>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
+            return mi355_check_launch("attn_fwd(prescaled)");
+        }
+    }
+    return launch_fwd<ND, NO>(a, s);
+}
 template <int ND, int NO>
 static int launch_bwd(const AttnArgs& a, hipStream_t s) {
     // dQ first: it writes delta (row sums of dO * O), which the dK/dV pass consumes
@@ -691,6 +740,21 @@ int mi355_attention_fwd(const void* q, const void* k, const void* v, void* out, 
     if (int rc = check_attn(a)) return rc;
     ProfScope prof(FAM_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Nq * Nk * D);
     return ATTN_DISPATCH(launch_fwd, a, (hipStream_t)stream);
+}
+
+// Forward on queries that already carry the softmax scale and the change of base: scores = q k^T are exponents of 2
+// (the caller folded scale * log2(e) into q, e.g. into the weights of the projection that produced it).  Same result
+// as mi355_attention_fwd on the unscaled q up to the rounding of q; lse in log2 units as everywhere.
+int mi355_attention_fwd_prescaled(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Nq,
+                                  int Nk, int D, int ldq, int ldk, int ldv, int ldo, void* stream) {
+    if (!q || !k || !v || !out) return mi355_fail(MI355_ERR_ARG, "attention_fwd_prescaled: null pointer");
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)out; a.lse = lse;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.scale = 0.6931471805599453f; a.scale_log2 = 1.f;
+    if (int rc = check_attn(a)) return rc;
+    ProfScope prof(FAM_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Nq * Nk * D);
+    return ATTN_DISPATCH(launch_fwd_ps, a, (hipStream_t)stream);
 }
 
 // Forward with a key-padding mask given as valid key counts per sample (1 <= kv_len[b] <= Nk, device int32).

@@ -1639,7 +1639,9 @@ static int launch_gemm_dma(const GemmArgs& a, unsigned a_bytes, unsigned b_bytes
 
 static int pick_splitk(int tiles, int nkt, double out_elems, int bn) {
     static const int capacity = getenv("MI355_GEMM_SK_CAP") ? atoi(getenv("MI355_GEMM_SK_CAP")) : 512;
-    const double t_tile = (bn == 160 ? 1.0 : bn == 128 ? 0.8 : 0.45);
+    static const double sk_pen = getenv("MI355_GEMM_SK_PEN") ? atof(getenv("MI355_GEMM_SK_PEN")) : 2.5;
+    static const double tt_scale = getenv("MI355_GEMM_SK_TT") ? atof(getenv("MI355_GEMM_SK_TT")) : 1.0;
+    const double t_tile = tt_scale * (bn == 160 ? 1.0 : bn == 128 ? 0.8 : 0.45);
     int best = 1;
     double best_t = 1e30;
     const int smax = nkt / 2 < 16 ? (nkt / 2 < 1 ? 1 : nkt / 2) : 16;
@@ -1649,7 +1651,7 @@ static int pick_splitk(int tiles, int nkt, double out_elems, int bn) {
         if (se != s) continue;
         const double waves = (double)((tiles * s + capacity - 1) / capacity);
         double t = waves * kps * t_tile + 2.0;
-        if (s > 1) t += 2.5 + 2.0 * s * out_elems * 4.0 / 4.0e6;   // slab write + read at ~4 TB/s, + launch
+        if (s > 1) t += sk_pen + 2.0 * s * out_elems * 4.0 / 4.0e6;   // slab write + read at ~4 TB/s, + launch
         if (t < best_t) { best_t = t; best = s; }
     }
     return best;

@@ -712,18 +712,19 @@ static int gn_geometry(int HW, int C, int G, int* threads, int* rpar, int* rows_
     return 0;
 }
 
-// LayerNorm folded into the product behind it: W' = bf16(gamma (.) W), colsum[n] = sum_k W'[n][k] (of the rounded
-// values the matrix pipe will multiply), bias'[n] = sum_k beta[k] W[n][k] + bias[n].  One workgroup per output row n.
+// LayerNorm folded into the product behind it: W' = bf16(scale gamma (.) W), colsum[n] = sum_k W'[n][k] (of the rounded
+// values the matrix pipe will multiply), bias'[n] = scale (sum_k beta[k] W[n][k] + bias[n]).  One workgroup per output row
+// n.  scale: a factor on the layer's output folded in as well (the softmax scale of an attention's query projection).
 __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ bias,
                                                              bf16_t* __restrict__ Wp, float* __restrict__ colsum,
-                                                             float* __restrict__ bias_out, int K) {
+                                                             float* __restrict__ bias_out, int K, float scale) {
     __shared__ float red[16];
     const int n = blockIdx.x;
     float cs = 0.f, bb = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float w = W[(size_t)n * ldw + k];
-        const bf16_t wp = (bf16_t)(gamma[k] * w);
+        const bf16_t wp = (bf16_t)(scale * gamma[k] * w);
         Wp[(size_t)n * K + k] = wp;
         cs += (float)wp;
         bb += beta[k] * w;
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const float* __rest
     bb = block_sum(bb, red);
     if (threadIdx.x == 0) {
         colsum[n] = cs;
-        bias_out[n] = bb + (bias ? bias[n] : 0.f);
+        bias_out[n] = scale * (bb + (bias ? bias[n] : 0.f));
     }
 }
 
@@ -991,11 +992,11 @@ int mi355_reduce_rows_batched(const long long* table, int n, int max_cols, void*
 
 
 int mi355_ln_fold_weight(const float* W, int ldw, const float* gamma, const float* beta, const float* bias, void* Wp,
-                         float* colsum, float* bias_out, int N, int K, void* stream) {
+                         float* colsum, float* bias_out, int N, int K, float scale, void* stream) {
     if (!W || !gamma || !beta || !Wp || !colsum || !bias_out || N < 1 || K < 1 || ldw < K)
         return mi355_fail(MI355_ERR_ARG, "ln_fold_weight: bad arguments");
     hipLaunchKernelGGL(ln_fold_weight_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, W, ldw, gamma, beta, bias, (bf16_t*)Wp,
-                       colsum, bias_out, K);
+                       colsum, bias_out, K, scale);
     return mi355_check_launch("ln_fold_weight");
 }
 }  // extern "C"

@@ -173,10 +173,10 @@ def gemm_rowstats(a, w, bias=None, residual=None):
     return out, stat.view(-1)[:M * parts.value * 2].view(M, parts.value, 2), parts.value
 
 
-def ln_fold_weight(weight, gamma, beta, bias=None, out=None):
+def ln_fold_weight(weight, gamma, beta, bias=None, out=None, scale=1.0):
     """(wp, colsum, bias_out) for `gemm_ln`: the fp32 weight [N][K] of the layer behind a LayerNorm with that norm's
     gamma / beta folded in (see mi355_ln_fold_weight).  out: the three destinations (row slices of larger buffers when
-    several layers share the norm and run as one product)."""
+    several layers share the norm and run as one product).  scale: a factor on the layer's output folded in too."""
     N, K = weight.shape
     assert weight.dtype == F32 and weight.stride(1) == 1
     if out is not None:
@@ -187,7 +187,7 @@ def ln_fold_weight(weight, gamma, beta, bias=None, out=None):
         cs = torch.empty(N, dtype=F32, device=weight.device)
         bo = torch.empty(N, dtype=F32, device=weight.device)
     check(lib.mi355_ln_fold_weight(weight.data_ptr(), weight.stride(0), gamma.data_ptr(), beta.data_ptr(), _ptr(bias),
-                                   wp.data_ptr(), cs.data_ptr(), bo.data_ptr(), N, K, _stream()), "ln_fold_weight")
+                                   wp.data_ptr(), cs.data_ptr(), bo.data_ptr(), N, K, float(scale), _stream()), "ln_fold_weight")
     return wp, cs, bo
 
 
@@ -570,9 +570,13 @@ def colsum(y2d, seg=None):
     return out
 
 
-def attention_fwd(q, k, v, heads, kv_len=None):
+ATTN_PRESCALE = 1.4426950408889634       # log2(e): a prescaled query carries head_dim ** -0.5 * ATTN_PRESCALE
+
+
+def attention_fwd(q, k, v, heads, kv_len=None, prescaled=False):
     """q [B,Nq,C], k/v [B,Nk,C] (last dim contiguous; row stride arbitrary multiple of 8).
-    kv_len: optional int32 [B] device tensor, keys >= kv_len[b] are masked (key-padding mask)."""
+    kv_len: optional int32 [B] device tensor, keys >= kv_len[b] are masked (key-padding mask).
+    prescaled: q already carries head_dim ** -0.5 * log2(e) (mi355_attention_fwd_prescaled; no gradient path)."""
     B, Nq, C = q.shape
     Nk = k.shape[1]
     D = C // heads
@@ -583,6 +587,11 @@ def attention_fwd(q, k, v, heads, kv_len=None):
         check(lib.mi355_attention_fwd_masked(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
                                              kv_len.data_ptr(), B, heads, Nq, Nk, D, q.stride(1), k.stride(1), v.stride(1),
                                              C, 1.0 / math.sqrt(D), _stream()), "attention_fwd_masked")
+        return out, lse
+    if prescaled:
+        check(lib.mi355_attention_fwd_prescaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B,
+                                                heads, Nq, Nk, D, q.stride(1), k.stride(1), v.stride(1), C, _stream()),
+              "attention_fwd_prescaled")
         return out, lse
     check(lib.mi355_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, heads,
                                   Nq, Nk, D, q.stride(1), k.stride(1), v.stride(1), C, 1.0 / math.sqrt(D), _stream()),

@@ -388,11 +388,14 @@ class BasicTransformerBlock(nn.Module):
             C, dev = a1.to_q.weight.shape[1], a1.to_q.weight.device
             wp = torch.empty((3 * C, C), dtype=BF16, device=dev)
             cs, bo = torch.empty(3 * C, dtype=F32, device=dev), torch.empty(3 * C, dtype=F32, device=dev)
+            # the query projections also carry the softmax scale and the change of base (ops.attention_fwd, prescaled)
+            qs = (C // a1.heads) ** -0.5 * ops.ATTN_PRESCALE
             for i, m in enumerate((a1.to_q, a1.to_k, a1.to_v)):
                 sl = slice(i * C, (i + 1) * C)
                 ops.ln_fold_weight(m.weight.detach(), self.norm1.weight.detach(), self.norm1.bias.detach(), None,
-                                   out=(wp[sl], cs[sl], bo[sl]))
-            q = ops.ln_fold_weight(a2.to_q.weight.detach(), self.norm2.weight.detach(), self.norm2.bias.detach(), None)
+                                   out=(wp[sl], cs[sl], bo[sl]), scale=qs if i == 0 else 1.0)
+            q = ops.ln_fold_weight(a2.to_q.weight.detach(), self.norm2.weight.detach(), self.norm2.bias.detach(), None,
+                                   scale=(C // a2.heads) ** -0.5 * ops.ATTN_PRESCALE)
             f = ops.ln_fold_weight(g.weight.detach(), self.norm3.weight.detach(), self.norm3.bias.detach(), g.bias.detach())
             self._fold, self._fold_sig = ((wp, cs, bo), q, f), sig
         return self._fold
@@ -406,11 +409,12 @@ class BasicTransformerBlock(nn.Module):
         (w1, c1, b1), (w2, c2, b2), (w3, c3, b3) = self._folded()
         x0 = x.view(B * N, C)
         qkv = ops.gemm_ln(x0, w1, c1, b1, stat, parts, self.norm1.eps).view(B, N, 3 * C)
-        a = AttentionFn.apply(qkv, None, None, a1.heads).view(B * N, C)
+        a = ops.attention_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], a1.heads, prescaled=True)[0].view(B * N, C)
         p = a1.to_out[0].pack
         x1, st1, p1 = ops.gemm_rowstats(a, p.w16.view(p.n, p.k), bias=a1.to_out[0].bias, residual=x0)
         q = ops.gemm_ln(x1, w2, c2, b2, st1, p1, self.norm2.eps).view(B, N, C)
-        a = AttentionFn.apply(q, a2.context_kv(context), None, a2.heads).view(B * N, C)
+        kv = a2.context_kv(context)
+        a = ops.attention_fwd(q, kv[:, :, :C], kv[:, :, C:], a2.heads, prescaled=True)[0].view(B * N, C)
         p = a2.to_out[0].pack
         x2, st2, p2 = ops.gemm_rowstats(a, p.w16.view(p.n, p.k), bias=a2.to_out[0].bias, residual=x1)
         h = ops.gemm_ln(x2, w3, c3, b3, st2, p2, self.norm3.eps, geglu=True)

@@ -146,7 +146,9 @@ int mi355_groupnorm_fwd_two_pass(int HW, int C, int G);
  *       *parts_out (host int) = the number of column tiles taken (N / 160 or N / 320); rowstat holds M * (N / 160) * 2
  *       floats.  N % 160 == 0, K % 64 == 0.
  *   mi355_ln_fold_weight: from a layer's fp32 weight W [N][K] (row stride ldw), its bias (or NULL) and the norm's gamma /
- *       beta [K]: Wp = bf16(gamma (.) W) [N][K], colsum[n] = sum_k Wp[n][k], bias_out[n] = sum_k beta[k] W[n][k] + bias[n].
+ *       beta [K]: Wp = bf16(scale gamma (.) W) [N][K], colsum[n] = sum_k Wp[n][k], bias_out[n] = scale (sum_k beta[k]
+ *       W[n][k] + bias[n]); scale: a factor on the layer's output folded in as well (1, or the softmax scale times log2(e)
+ *       for a query projection whose attention runs through mi355_attention_fwd_prescaled).
  *   mi355_gemm_ln_bf16: out = LayerNorm(A) W^T + b computed as rstd * (A Wp^T - mean * colsum) + bias_out, with mean and
  *       rstd of each row of A [M][K] from ln_part [M][ln_nparts][2] (the partial sums above; K values per row, eps as
  *       the norm's).  geglu != 0: N = 2F weight rows (hidden | gate), out [M][F] = h * gelu(g) as mi355_gemm_geglu_bf16. */
@@ -154,7 +156,7 @@ int mi355_gemm_rowstats_bf16(const void* A, int lda, const void* Bw, int ldb, in
                              const float* bias, const void* residual, int ldr, float* rowstat, int* parts_out,
                              void* workspace, size_t workspace_bytes, void* stream);
 int mi355_ln_fold_weight(const float* W, int ldw, const float* gamma, const float* beta, const float* bias, void* Wp,
-                         float* colsum, float* bias_out, int N, int K, void* stream);
+                         float* colsum, float* bias_out, int N, int K, float scale, void* stream);
 int mi355_gemm_ln_bf16(const void* A, int lda, const void* Bw, int ldb, int M, int N, int K, void* out, int ldo,
                        const float* bias, const float* ln_part, int ln_nparts, const float* colsum, float eps, int geglu,
                        void* workspace, size_t workspace_bytes, void* stream);
@@ -227,6 +229,14 @@ int mi355_colsum_bf16(const void* y, float* out, float* scratch, int M, int N, i
  * (image_generator.py:124 passes none).  lse [B][H][Nq] receives log2-domain row statistics. */
 int mi355_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Nq,
                         int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+/* The same forward on queries that already carry the softmax scale and the change of base (q' = q * scale * log2(e),
+ * folded by the caller into the projection that produces q - the no-gradient denoiser call of image_generator.py:92-95
+ * folds it into the LayerNorm-folded query weights): scores q' k^T are exponents of 2.  Heads with a spare padding column
+ * (D < 32 or 32 < D < 64) run a key loop without a running maximum (a workgroup whose row sums leave 2^-100 .. 2^100
+ * repeats its loop with one); other head sizes take the plain kernel.  Results equal mi355_attention_fwd's up to the
+ * rounding of q'. */
+int mi355_attention_fwd_prescaled(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Nq,
+                                  int Nk, int D, int ldq, int ldk, int ldv, int ldo, void* stream);
 /* Forward with a key-padding mask (encoder/text_encoder.py:31-34 `src_key_padding_mask=~attention_mask`), given as
  * the number of valid (leading) keys of each sample: kv_len [B] int32 on the device, 1 <= kv_len[b] <= Nk. */
 int mi355_attention_fwd_masked(const void* q, const void* k, const void* v, void* out, float* lse, const int* kv_len,

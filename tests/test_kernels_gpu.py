@@ -263,6 +263,50 @@ def test_attention_softmax_spike():
     close(o, ref, 2 ** -6, 1e-2, "attn spike")
 
 
+@pytest.mark.parametrize("B,H,N,T,D", [(2, 8, 1024, 1024, 40), (2, 4, 300, 77, 40), (1, 3, 515, 700, 56), (2, 2, 200, 130, 24),
+                                       (1, 4, 256, 256, 80), (1, 2, 64, 77, 160), (1, 2, 100, 100, 32)])
+def test_attention_on_prescaled_queries(B, H, N, T, D):
+    """mi355_attention_fwd_prescaled (queries that carry scale * log2(e); no running maximum in the key loop for heads
+    with a padding column, the plain kernel for the others) against fp32 softmax(q k^T / sqrt(d)) v on the unscaled
+    queries and against the plain entry: same tolerance as the plain kernel, log-sum-exp rows equal to 2e-2 (log2 units;
+    the prescaled query is rounded to bf16 once more)."""
+    from image_generator_amd import ops
+    C = H * D
+    q, k, v = rnd(B, N, C, seed=31), rnd(B, T, C, seed=32), rnd(B, T, C, seed=33)
+    ref = _attn_ref(q.float(), k.float(), v.float(), H)
+    qs = (q.float() * (D ** -0.5 * ops.ATTN_PRESCALE)).to(BF)
+    o, lse = ops.attention_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), H, prescaled=True)
+    o0, lse0 = ops.attention_fwd(q.to(dev()), k.to(dev()), v.to(dev()), H)
+    close(o, ref, 2 ** -6, 1e-2, "attn prescaled")
+    assert rel_l2(o, ref) < 6e-3
+    assert (lse - lse0).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("gain,shift", [(40.0, 0.0), (1.0, -300.0), (1.0, 300.0), (25.0, -150.0)])
+def test_attention_on_prescaled_queries_leaves_the_fast_range(gain, shift):
+    """Scores far outside +-100 (log2 units): huge positive ones overflow the loop without a running maximum, hugely
+    negative ones underflow it - the workgroup must notice from its row sums and repeat the loop with the maximum.
+    shift: a common offset on every score of a row (one extra channel: q = shift, k = 1) - softmax does not see it."""
+    from image_generator_amd import ops
+    B, H, N, D = 1, 2, 300, 40
+    C = H * D
+    q, k, v = rnd(B, N, C, seed=34).float() * gain, rnd(B, N, C, seed=35).float(), rnd(B, N, C, seed=36)
+    q = q.view(B, N, H, D); k = k.view(B, N, H, D)
+    q[..., 0] = shift; k[..., 0] = 1.0               # (bf16-exact values)
+    q, k = q.reshape(B, N, C).to(BF), k.reshape(B, N, C).to(BF)
+    # the prescaled operand is what the kernel is given; the reference divides the scale out again so both see the same q
+    c = D ** -0.5 * ops.ATTN_PRESCALE
+    qs = q.to(BF)
+    ref = _attn_ref(qs.float() / c, k.float(), v.float(), H)
+    o, lse = ops.attention_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), H, prescaled=True)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    s = torch.einsum("bnhd,bmhd->bhnm", qs.float().view(B, N, H, D), k.float().view(B, N, H, D))
+    assert s.abs().max().item() > 150.0               # the case really leaves the range
+    close(o, ref, 2 ** -6, 2e-2, "attn prescaled, extreme scores")
+    lse_ref = torch.logsumexp(s * math.log(2.0), -1) / math.log(2.0)
+    assert ((lse.cpu() - lse_ref).abs() / lse_ref.abs().clamp_min(1.0)).max().item() < 1e-2
+
+
 def test_geglu_and_silu():
     from image_generator_amd.ops import GegluFn, SiluF32ToBf16Fn
     x, dy = rnd(300, 2 * 640, seed=27), rnd(300, 640, seed=28)

@@ -74,5 +74,10 @@ if __name__ == "__main__":
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--tune", type=int, nargs=2, action="append", default=[], metavar=("KEY", "VALUE"),
+                    help="mi355_tune_set(KEY, VALUE) before the run (kernel-variant switches, for A/B on one box)")
     a = ap.parse_args()
+    for key, value in a.tune:
+        from image_generator_amd._lib import lib
+        lib.mi355_tune_set(key, value)
     (sampler if a.mode == "sampler" else lora)(a)
