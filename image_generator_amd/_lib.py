@@ -69,6 +69,10 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # MI355_TUNE="key:value,..." -> mi355_tune_set (kernel-variant switches of the launchers, for A/B runs of whole programs)
+    for item in filter(None, os.environ.get("MI355_TUNE", "").split(",")):
+        key, value = item.split(":")
+        lib.mi355_tune_set(int(key), int(value))
     return lib
 
 

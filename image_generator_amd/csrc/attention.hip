@@ -370,14 +370,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 // =============================================================================================
 // backward: dK, dV.  Workgroup = 128 keys of one (b,h) (32 per wave); loops over 64-query tiles.
 // =============================================================================================
-template <int ND, int NO, bool DROP = false>
+// FQ (at most 128 keys: the workgroup holds every key of its head): the whole backward in this one launch.  dQ contracts
+// over the keys, which sit on the lanes here, so dS crosses the LDS once ([key][32 queries] per 32-query sub-tile, written
+// as four 8-byte runs per lane, read back by transposing reads as the B operand of dQ^T = K^T dS^T, K staged once as a
+// [key][d] tile); the (sub-tile, 32-wide d block) units of a staged tile are dealt to the four waves.  delta = rowsum(dO o)
+// is computed while a tile is staged.  Replaces a dQ launch that recomputes S and dP (the 64- and 16-token levels and all
+// the text cross-attentions of the denoiser: 77 keys).
+template <int ND, int NO, bool DROP = false, bool FQ = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p) {
     constexpr int TLD = tr_ld(NO);      // Q / dO tiles [QT][NO*32], row + transposed reads
     constexpr int QT = NO <= 2 ? 128 : 64;   // queries per staged tile (32-query MFMA sub-tiles between one barrier pair)
-    __shared__ __attribute__((aligned(16))) char smem[2 * QT * TLD + 2 * QT * 4];
+    constexpr int DLD = 64 + 16;        // dS rows: 32 queries + padding (80 B: transposing reads of rows 4 apart hit distinct banks)
+    constexpr int FQ_BYTES = FQ ? 128 * TLD + (QT / 32) * 128 * DLD : 0;
+    __shared__ __attribute__((aligned(16))) char smem[2 * QT * TLD + 2 * QT * 4 + FQ_BYTES];
     char* Qs = smem;
     char* Gs = smem + QT * TLD;
     float* Ls = (float*)(smem + 2 * QT * TLD);   // lse2[QT], delta[QT]
+    char* Kt = smem + 2 * QT * TLD + 2 * QT * 4;  // FQ: K [128 keys][NO*32] (swizzled as the dQ kernel's K tile)
+    char* Ds = Kt + 128 * TLD;                    // FQ: dS [QT / 32][128 keys][32 queries]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -424,14 +434,42 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
     constexpr int NCQ = (QT * NO * 4 + 255) / 256;
     bf16x8 qreg[NCQ], greg[NCQ];
     float lreg = 0.f;
+    float dreg = 0.f;       // FQ: this thread's row sum of dO * o (256 / QT threads per query row)
     auto load_stats = [&](int q0) {
-        if (threadIdx.x < 2 * QT) {
+        if (FQ) {
+            constexpr int TPR = 256 / QT;
+            const int qi = q0 + threadIdx.x / TPR;
+            dreg = 0.f;
+            if (qi < p.Nq) {
+                const bf16_t* Or = p.o + ((size_t)b * p.Nq + qi) * p.ldo + h * p.D;
+                const bf16_t* Gr = Gb + (size_t)qi * p.ldo;
+                for (int c = threadIdx.x % TPR; c * 8 < p.D; c += TPR) {
+                    const bf16x8 ov = *(const bf16x8*)(Or + c * 8), gv = *(const bf16x8*)(Gr + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dreg += (float)ov[e] * (float)gv[e];
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < TPR; off <<= 1) dreg += __shfl_xor(dreg, off, 64);
+            if (threadIdx.x < QT) {
+                const int ql = q0 + threadIdx.x;
+                lreg = ql < p.Nq ? lse[ql] : INFINITY;
+            }
+        } else if (threadIdx.x < 2 * QT) {
             const int qi = q0 + (threadIdx.x & (QT - 1));
             lreg = 0.f;
             if (qi < p.Nq) lreg = threadIdx.x < QT ? lse[qi] : dlt[qi];
             else if (threadIdx.x < QT) lreg = INFINITY;     // padded query rows: p = exp2(-inf) = 0
         }
     };
+    if constexpr (FQ) {      // every key of the head, once: [key][d], rows past the valid keys zero (they add nothing to dQ)
+        constexpr int NCK = (128 * NO * 4 + 255) / 256;
+        bf16x8 kreg[NCK];
+        TileFetch<NCK> kfetch;
+        kfetch.template init<false>(Kb, p.ldk, p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk, p.D, 128, NO * 4);
+        kfetch.template load<false>(kreg, 0);
+        tile_store<NCK, true>(kreg, Kt, TLD, 128, NO * 4);
+    }
     TileFetch<NCQ> qfetch, gfetch;
     qfetch.template init<false>(Qb, p.ldq, p.Nq, p.D, QT, NO * 4);
     gfetch.template init<false>(Gb, p.ldo, p.Nq, p.D, QT, NO * 4);
@@ -443,7 +481,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
         __syncthreads();
         tile_store<NCQ, true>(qreg, Qs, TLD, QT, NO * 4);
         tile_store<NCQ, true>(greg, Gs, TLD, QT, NO * 4);
-        if (threadIdx.x < 2 * QT) Ls[threadIdx.x] = lreg;
+        if (FQ) {
+            if (threadIdx.x < QT) Ls[threadIdx.x] = lreg;
+            if (threadIdx.x % (256 / QT) == 0) Ls[QT + threadIdx.x / (256 / QT)] = dreg;
+        } else if (threadIdx.x < 2 * QT) Ls[threadIdx.x] = lreg;
         __syncthreads();
         if (qt + 1 < nqt) {
             qfetch.template load<false>(qreg, q0 + QT);
@@ -485,6 +526,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
             pf[r >> 3][r & 7] = (bf16_t)pd;
             dsf[r >> 3][r & 7] = (bf16_t)dsv;
         }
+        if constexpr (FQ) {     // dS of this wave's 32 keys x 32 queries -> LDS [key][query]; a masked key contributes nothing
+            char* row = Ds + (qs * 128 + wave * 32 + l31) * DLD + hh * 8;
+            const bf16x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v4 = {dsf[g >> 1][(g & 1) * 4], dsf[g >> 1][(g & 1) * 4 + 1], dsf[g >> 1][(g & 1) * 4 + 2],
+                             dsf[g >> 1][(g & 1) * 4 + 3]};
+                *(bf16x4*)(row + g * 16) = k_valid ? v4 : z4;
+            }
+        }
 #pragma unroll
         for (int db = 0; db < NO; ++db)
 #pragma unroll
@@ -494,6 +545,39 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnArgs p)
                 dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, pf[st], dvT[db], 0, 0, 0);
                 const bf16x8 aq = cat4(LDS_TR(Qt + off + tr_c0), LDS_TR(Qt + off + 8 * TLD + tr_c1));
                 dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, dsf[st], dkT[db], 0, 0, 0);
+            }
+        }
+        if constexpr (FQ) {
+            __syncthreads();                    // every wave's dS of this staged tile is in LDS
+            const int nkb = (p.Nk + 31) / 32;   // 32-key blocks that hold keys
+            for (int u = wave; u < (QT / 32) * NO; u += 4) {
+                const int qs = u / NO, db = u - qs * NO;
+                const int qrow = q0 + qs * 32 + l31;
+                if (q0 + qs * 32 >= p.Nq) break;        // (uniform) units are ordered by sub-tile
+                f32x16 dq;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+                for (int kb = 0; kb < nkb; ++kb)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const int krow = kb * 32 + 16 * st + tr_row;
+                        const bf16x8 ak = cat4(LDS_TR(Kt + krow * TLD + db * 64 + tr_c0), LDS_TR(Kt + (krow + 8) * TLD + db * 64 + tr_c1));
+                        const char* d0 = Ds + (qs * 128 + krow) * DLD + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+                        const bf16x8 bd = cat4(LDS_TR(d0), LDS_TR(d0 + 8 * DLD));
+                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, bd, dq, 0, 0, 0);
+                    }
+                if (qrow < p.Nq) {
+                    bf16_t* dQ = p.dq + ((size_t)b * p.Nq + qrow) * p.ldq + h * p.D;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = db * 32 + 8 * g + 4 * hh;
+                        if (d < p.D) {
+                            bf16x4 a = {(bf16_t)(dq[4 * g] * p.scale), (bf16_t)(dq[4 * g + 1] * p.scale),
+                                        (bf16_t)(dq[4 * g + 2] * p.scale), (bf16_t)(dq[4 * g + 3] * p.scale)};
+                            *(bf16x4*)(dQ + d) = a;
+                        }
+                    }
+                }
             }
         }
     }
@@ -682,6 +766,10 @@ static int launch_fwd_ps(const AttnArgs& a, hipStream_t s) {
 }
 template <int ND, int NO>
 static int launch_bwd(const AttnArgs& a, hipStream_t s) {
+    if (a.Nk <= 128 && mi355_g_tune[1] != 1) {       // one launch (mi355_tune_set(1, 1): two, for A/B inside one process)
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<ND, NO, false, true>), dim3(1, a.B * a.H), dim3(256), 0, s, a);
+        return mi355_check_launch("attn_bwd(one launch)");
+    }
     // dQ first: it writes delta (row sums of dO * O), which the dK/dV pass consumes
     hipLaunchKernelGGL((attn_bwd_dq_kernel<ND, NO>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<ND, NO>), dim3((a.Nk + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
