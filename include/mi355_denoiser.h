@@ -242,7 +242,9 @@ int mi355_attention_fwd_prescaled(const void* q, const void* k, const void* v, v
 int mi355_attention_fwd_masked(const void* q, const void* k, const void* v, void* out, float* lse, const int* kv_len,
                                int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo, float scale,
                                void* stream);
-/* Backward: delta [B][H][Nq] is scratch; dq uses ldq, dout / o use ldo.  dk / dv are written with row strides lddk / lddv
+/* Backward: delta [B][H][Nq] is scratch (row sums of dout * o, produced by the dQ launch for the dK / dV launch; with at
+ * most 128 keys one launch computes dQ, dK and dV and leaves it untouched); dq uses ldq, dout / o use ldo.  dk / dv are
+ * written with row strides lddk / lddv
  * (0: ldk / ldv): keys and values that are column slices of a wider matrix - the text keys / values of all
  * cross-attention layers come out of one product - can have contiguous gradients. */
 int mi355_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
