@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence on one box: kernel-trace summaries of the headline bench, the sampling loop and the LoRA step, then the
+# The evidence kept under profiles/, collected on one box: kernel-trace summaries of the headline bench, the sampling loop and the LoRA step, then the
 # counter passes (HBM-side traffic, matrix-pipe utilisation) over the eager train step.  usage: tools/r3_final_profiles.sh <tag>
 cd $GRAFT_REPO_ROOT
 tag=${1:-r03}
