@@ -367,6 +367,183 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
 }
 
+// The prescaled forward for long sequences: a wave owns TWO 32-query blocks (a workgroup 256 queries), so every staged K / V
+// tile and every K / V^T fragment read from LDS serves twice the queries, and a wave has four independent accumulator
+// chains.  With the running maximum in the loop this form gained 1 % (202 registers, two waves per SIMD: the loop was bound
+// by vector issue); without it the fragment reads and the staging are what is left, and it gains 9 % at 4 096 tokens
+// (1 128 -> 1 029 us per launch at d = 40) - and loses 6 % at 1 024, where it halves an already small grid.  Same
+// fall-back as the one-block form: a workgroup whose row sums leave 2^-100 .. 2^100 repeats its loop with the maximum.
+template <int ND, int NO>
+__global__ __launch_bounds__(256, 2) void attn_fwd_ps2_kernel(const AttnArgs p) {
+    constexpr int DP = 16 * ND;
+    constexpr int KLD = DP * 2 + 16;
+    constexpr int VLD = tr_ld(NO);
+    __shared__ __attribute__((aligned(16))) char smem[64 * KLD + 64 * VLD];
+    char* Ks = smem;
+    char* Vs = smem + 64 * KLD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wg_x = blockIdx.x, wg_y = blockIdx.y;
+    const int b = wg_y / p.H, h = wg_y % p.H;
+    const int q0 = wg_x * 256 + wave * 64;
+    const bf16_t* Qb = p.q + (size_t)b * p.Nq * p.ldq + h * p.D;
+    const bf16_t* Kb = p.k + (size_t)b * p.Nk * p.ldk + h * p.D;
+    const bf16_t* Vb = p.v + (size_t)b * p.Nk * p.ldv + h * p.D;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 qf[2][ND];
+    f32x16 o[2][NO];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0 + qb * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < ND; ++ks) {
+            const int d = ks * 16 + 8 * hh;
+            qf[qb][ks] = (qrow < p.Nq && d < p.D) ? *(const bf16x8*)(Qb + (size_t)qrow * p.ldq + d) : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < NO; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+    }
+    const int Nk = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;
+    const int nkt = (Nk + 63) / 64;
+    constexpr int NCK = (64 * (DP / 8) + 255) / 256, NCV = (64 * NO * 4 + 255) / 256;
+    bf16x8 kreg[NCK], vreg[NCV];
+    TileFetch<NCK> kfetch;
+    TileFetch<NCV> vfetch;
+    kfetch.template init<false>(Kb, p.ldk, Nk, p.D, 64, DP / 8);
+    vfetch.template init<true>(Vb, p.ldv, Nk, p.D, 64, NO * 4);
+    const int tr_row = 4 * hh + ((lane & 15) >> 2);
+    const int tr_col = (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+    float m[2] = {0.f, 0.f};
+    auto run_tiles = [&](auto fast_c) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    kfetch.template load<false>(kreg, 0);
+    vfetch.template load<true>(vreg, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 64;
+        __syncthreads();
+        tile_store(kreg, Ks, KLD, 64, DP / 8);
+        tile_store(vreg, Vs, VLD, 64, NO * 4);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            kfetch.template load<false>(kreg, k0 + 64);
+            vfetch.template load<true>(vreg, k0 + 64);
+        }
+        bf16x8 kf[2][ND];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < ND; ++ks)
+                kf[kb][ks] = *(const bf16x8*)(Ks + (kb * 32 + l31) * KLD + (ks * 16 + 8 * hh) * 2);
+        f32x16 s[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < ND; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[qb][ks], s[qb][kb], 0, 0, 0);
+        if (k0 + 64 > Nk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= Nk) { s[0][kb][r] = -INFINITY; s[1][kb][r] = -INFINITY; }
+                }
+        }
+        bf16x8 pf[2][2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float sub = 0.f;
+            if constexpr (!FAST) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m[qb], mx);
+                const float alpha = EXP2(m[qb] - m_new);
+                if (__builtin_amdgcn_ballot_w64(m_new != m[qb]) != 0) {
+#pragma unroll
+                    for (int i = 0; i < NO; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+                }
+                m[qb] = m_new;
+                sub = m_new;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        pf[qb][kb][st][j] = (bf16_t)EXP2(FAST ? s[qb][kb][8 * st + j] : s[qb][kb][8 * st + j] - sub);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int db = 0; db < NO; ++db) {
+                    const char* a0 = Vs + (kb * 32 + 16 * st + tr_row) * VLD + db * 64 + tr_col;
+                    const bf16x8 a = cat4(LDS_TR(a0), LDS_TR(a0 + 8 * VLD));
+                    o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[0][kb][st], o[0][db], 0, 0, 0);
+                    o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[1][kb][st], o[1][db], 0, 0, 0);
+                }
+    }
+    };
+    const int c = p.D & 31;
+    auto ones_sum = [&](int qb) {
+        const float lsum = c == 8 ? o[qb][NO - 1][4] : c == 16 ? o[qb][NO - 1][8] : o[qb][NO - 1][12];
+        return __shfl(lsum, l31, 64);
+    };
+    run_tiles(std::true_type{});
+    float lq[2] = {ones_sum(0), ones_sum(1)};
+    if (__syncthreads_or(!(lq[0] > 0x1p-100f && lq[0] < 0x1p100f && lq[1] > 0x1p-100f && lq[1] < 0x1p100f))) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int i = 0; i < NO; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+            m[qb] = -INFINITY;
+        }
+        run_tiles(std::false_type{});
+        lq[0] = ones_sum(0); lq[1] = ones_sum(1);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0 + qb * 32 + l31;
+        const float l = lq[qb];
+        if (qrow < p.Nq) {
+            const float inv = 1.f / l;
+            bf16_t* Ob = p.out + ((size_t)b * p.Nq + qrow) * p.ldo + h * p.D;
+#pragma unroll
+            for (int db = 0; db < NO; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = db * 32 + 8 * g + 4 * hh;
+                    if (d < p.D) {
+                        bf16x4 ov = {(bf16_t)(o[qb][db][4 * g] * inv), (bf16_t)(o[qb][db][4 * g + 1] * inv),
+                                     (bf16_t)(o[qb][db][4 * g + 2] * inv), (bf16_t)(o[qb][db][4 * g + 3] * inv)};
+                        *(bf16x4*)(Ob + d) = ov;
+                    }
+                }
+            if (hh == 0 && p.lse) p.lse[((size_t)b * p.H + h) * p.Nq + qrow] = m[qb] + log2f(l);
+        }
+    }
+}
+
 // =============================================================================================
 // backward: dK, dV.  Workgroup = 128 keys of one (b,h) (32 per wave); loops over 64-query tiles.
 // =============================================================================================
@@ -757,6 +934,11 @@ static int launch_fwd(const AttnArgs& a, hipStream_t s) {
 template <int ND, int NO>
 static int launch_fwd_ps(const AttnArgs& a, hipStream_t s) {
     if constexpr (NO <= 2) {      // (d = 80 in three 32-wide blocks: measured, +-0 in the sampling step)
+        // long sequences: 64 queries per wave.  mi355_tune_set(0, 2): never, (0, 3): whenever the kernel applies
+        if (a.D < 32 * NO && mi355_g_tune[0] != 1 && mi355_g_tune[0] != 2 && ((a.Nq >= 2048 && a.Nk >= 1024) || mi355_g_tune[0] == 3)) {
+            hipLaunchKernelGGL((attn_fwd_ps2_kernel<ND, NO>), dim3((a.Nq + 255) / 256, a.B * a.H), dim3(256), 0, s, a);
+            return mi355_check_launch("attn_fwd(prescaled, 64 queries per wave)");
+        }
         if (a.D < 32 * NO && mi355_g_tune[0] != 1) {      // mi355_tune_set(0, 1): plain kernel (A/B inside one process)
             hipLaunchKernelGGL((attn_fwd_kernel<ND, NO, true, false, true>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), 0, s, a);
             return mi355_check_launch("attn_fwd(prescaled)");

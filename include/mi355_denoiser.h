@@ -233,7 +233,8 @@ int mi355_attention_fwd(const void* q, const void* k, const void* v, void* out, 
  * folded by the caller into the projection that produces q - the no-gradient denoiser call of image_generator.py:92-95
  * folds it into the LayerNorm-folded query weights): scores q' k^T are exponents of 2.  Heads with a spare padding column
  * (D < 32 or 32 < D < 64) run a key loop without a running maximum (a workgroup whose row sums leave 2^-100 .. 2^100
- * repeats its loop with one); other head sizes take the plain kernel.  Results equal mi355_attention_fwd's up to the
+ * repeats its loop with one), with 64 queries per wave from 2 048 queries and 1 024 keys on; other head sizes take the
+ * plain kernel.  Results equal mi355_attention_fwd's up to the
  * rounding of q'. */
 int mi355_attention_fwd_prescaled(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Nq,
                                   int Nk, int D, int ldq, int ldk, int ldv, int ldo, void* stream);

@@ -263,7 +263,7 @@ def test_attention_softmax_spike():
     close(o, ref, 2 ** -6, 1e-2, "attn spike")
 
 
-@pytest.mark.parametrize("B,H,N,T,D", [(2, 8, 1024, 1024, 40), (2, 4, 300, 77, 40), (1, 3, 515, 700, 56), (2, 2, 200, 130, 24),
+@pytest.mark.parametrize("B,H,N,T,D", [(1, 4, 2304, 2304, 40), (2, 8, 1024, 1024, 40), (2, 4, 300, 77, 40), (1, 3, 515, 700, 56), (2, 2, 200, 130, 24),
                                        (1, 4, 256, 256, 80), (1, 2, 64, 77, 160), (1, 2, 100, 100, 32)])
 def test_attention_on_prescaled_queries(B, H, N, T, D):
     """mi355_attention_fwd_prescaled (queries that carry scale * log2(e); no running maximum in the key loop for heads
@@ -275,11 +275,17 @@ def test_attention_on_prescaled_queries(B, H, N, T, D):
     q, k, v = rnd(B, N, C, seed=31), rnd(B, T, C, seed=32), rnd(B, T, C, seed=33)
     ref = _attn_ref(q.float(), k.float(), v.float(), H)
     qs = (q.float() * (D ** -0.5 * ops.ATTN_PRESCALE)).to(BF)
-    o, lse = ops.attention_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), H, prescaled=True)
     o0, lse0 = ops.attention_fwd(q.to(dev()), k.to(dev()), v.to(dev()), H)
-    close(o, ref, 2 ** -6, 1e-2, "attn prescaled")
-    assert rel_l2(o, ref) < 6e-3
-    assert (lse - lse0).abs().max().item() < 2e-2
+    from image_generator_amd._lib import lib
+    try:
+        for form in (2, 3):      # 32 queries per wave; 64 queries per wave (the long-sequence form, forced on every shape)
+            lib.mi355_tune_set(0, form)
+            o, lse = ops.attention_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), H, prescaled=True)
+            close(o, ref, 2 ** -6, 1e-2, "attn prescaled")
+            assert rel_l2(o, ref) < 6e-3
+            assert (lse - lse0).abs().max().item() < 2e-2
+    finally:
+        lib.mi355_tune_set(0, 0)
 
 
 @pytest.mark.parametrize("gain,shift", [(40.0, 0.0), (1.0, -300.0), (1.0, 300.0), (25.0, -150.0)])
@@ -298,13 +304,19 @@ def test_attention_on_prescaled_queries_leaves_the_fast_range(gain, shift):
     c = D ** -0.5 * ops.ATTN_PRESCALE
     qs = q.to(BF)
     ref = _attn_ref(qs.float() / c, k.float(), v.float(), H)
-    o, lse = ops.attention_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), H, prescaled=True)
-    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     s = torch.einsum("bnhd,bmhd->bhnm", qs.float().view(B, N, H, D), k.float().view(B, N, H, D))
     assert s.abs().max().item() > 150.0               # the case really leaves the range
-    close(o, ref, 2 ** -6, 2e-2, "attn prescaled, extreme scores")
     lse_ref = torch.logsumexp(s * math.log(2.0), -1) / math.log(2.0)
-    assert ((lse.cpu() - lse_ref).abs() / lse_ref.abs().clamp_min(1.0)).max().item() < 1e-2
+    from image_generator_amd._lib import lib
+    try:
+        for form in (2, 3):      # 32 and 64 queries per wave
+            lib.mi355_tune_set(0, form)
+            o, lse = ops.attention_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), H, prescaled=True)
+            assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+            close(o, ref, 2 ** -6, 2e-2, "attn prescaled, extreme scores")
+            assert ((lse.cpu() - lse_ref).abs() / lse_ref.abs().clamp_min(1.0)).max().item() < 1e-2
+    finally:
+        lib.mi355_tune_set(0, 0)
 
 
 def test_geglu_and_silu():
