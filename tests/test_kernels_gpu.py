@@ -319,6 +319,25 @@ def test_attention_on_prescaled_queries_leaves_the_fast_range(gain, shift):
         lib.mi355_tune_set(0, 0)
 
 
+def test_table_driven_copies():
+    """mi355_copy_ranges: n (source, destination, bytes) records in one launch; ranges of very different lengths, one of
+    them a single 16-byte unit, destinations untouched outside the ranges."""
+    from image_generator_amd._lib import lib, check
+    torch.manual_seed(41)
+    src = torch.randn(200_000, device=dev())
+    dst = torch.full((300_000,), -7.0, device=dev())
+    recs = [(0, 1000, 4), (4, 8, 100_000), (120_000, 150_004, 33_332), (199_996, 299_996, 4)]     # element offsets, lengths
+    table = torch.tensor([[src.data_ptr() + 4 * a, dst.data_ptr() + 4 * b, 4 * n] for a, b, n in recs], dtype=torch.int64,
+                         device=dev())
+    for blocks in (1, 64):
+        dst.fill_(-7.0)
+        check(lib.mi355_copy_ranges(table.data_ptr(), len(recs), blocks, torch.cuda.current_stream().cuda_stream), "copy_ranges")
+        want = torch.full_like(dst, -7.0)
+        for a, b, n in recs:
+            want[b:b + n] = src[a:a + n]
+        assert torch.equal(dst, want)
+
+
 def test_geglu_and_silu():
     from image_generator_amd.ops import GegluFn, SiluF32ToBf16Fn
     x, dy = rnd(300, 2 * 640, seed=27), rnd(300, 640, seed=28)
