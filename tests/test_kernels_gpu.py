@@ -263,7 +263,7 @@ def test_attention_softmax_spike():
     close(o, ref, 2 ** -6, 1e-2, "attn spike")
 
 
-@pytest.mark.parametrize("B,H,N,T,D", [(1, 4, 2304, 2304, 40), (2, 8, 1024, 1024, 40), (2, 4, 300, 77, 40), (1, 3, 515, 700, 56), (2, 2, 200, 130, 24),
+@pytest.mark.parametrize("B,H,N,T,D", [(1, 2, 4096, 4096, 40), (1, 4, 2304, 2304, 40), (2, 8, 1024, 1024, 40), (2, 4, 300, 77, 40), (1, 3, 515, 700, 56), (2, 2, 200, 130, 24),
                                        (1, 4, 256, 256, 80), (1, 2, 64, 77, 160), (1, 2, 100, 100, 32)])
 def test_attention_on_prescaled_queries(B, H, N, T, D):
     """mi355_attention_fwd_prescaled (queries that carry scale * log2(e); no running maximum in the key loop for heads
