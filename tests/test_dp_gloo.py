@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the bucketed gradient reducer of the data-parallel step."""
+"""CPU, world_size 2 and 4 over gloo: the bucketed gradient reducer of the data-parallel step."""
 import os
 import socket
 
@@ -79,8 +79,9 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_allreduce(world):
+    port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
@@ -90,9 +91,9 @@ def test_bucketed_allreduce_world2():
         want = sum(l.to(torch.bfloat16).float() for l in locs)        # bf16 pack, sum, unpack
         for r in range(world):
             got = out[(r, step)]
-            assert torch.allclose(got, want, rtol=2e-2, atol=2e-2)
+            assert torch.allclose(got, want, rtol=2e-2, atol=3e-2)
             assert torch.equal(out[(0, step)], got)                   # every rank holds the same reduced gradient
     n = 4096 + 1024 + 8192 + 512 + 2048 + 16384 + 640 + 300
     want = sum(torch.randn(n, generator=torch.Generator().manual_seed(300 + r)).to(torch.bfloat16).float() for r in range(world))
     for r in range(world):
-        assert torch.allclose(out[(r, 3)], want, rtol=2e-2, atol=2e-2)      # the packless bucket included
+        assert torch.allclose(out[(r, 3)], want, rtol=2e-2, atol=3e-2)      # the packless bucket included
