@@ -4,7 +4,7 @@ a rank it puts both processes on cuda:0 and carries rendezvous and collectives o
 refuses two ranks on one device).  Everything else - the launcher, the environment plumbing, the reducer, the timed loop,
 the per-rank times gathered to rank 0, the event-timed steps with collectives inside, rank 0 reporting while rank 1
 waits - is bench.py's own code.  The throughput it prints means nothing.
-usage: bench_two_ranks_rehearsal.py [bench.py arguments other than --gpus]"""
+usage: bench_two_ranks_rehearsal.py [--ranks N] [bench.py arguments other than --gpus]   (N ranks on the one GPU, default 2)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -45,8 +45,13 @@ if __name__ == "__main__":
     if "RANK" in os.environ:
         rank_main()
     else:
-        argv = ["--gpus", "2"] + sys.argv[1:]
-        # the launcher's own device count runs too; two ranks share the one GPU here, so one device is enough
-        rc = bench.launch_ranks(2, argv, entry=os.path.abspath(__file__), need_devices=1)
+        rest, ranks = sys.argv[1:], 2
+        if "--ranks" in rest:
+            i = rest.index("--ranks")
+            ranks = int(rest[i + 1])
+            rest = rest[:i] + rest[i + 2:]
+        argv = ["--gpus", str(ranks)] + rest
+        # the launcher's own device count runs too; the ranks share the one GPU here, so one device is enough
+        rc = bench.launch_ranks(ranks, argv, entry=os.path.abspath(__file__), need_devices=1)
         print("rehearsal finished, exit status", rc)
         sys.exit(rc)
