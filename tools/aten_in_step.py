@@ -20,7 +20,7 @@ ts = torch.randint(0, 1000, (B,), device=d)
 for _ in range(3):
     tr.train_step(lat, noise, ts, ctx)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     tr.train_step(lat, noise, ts, ctx)
     torch.cuda.synchronize()
 rows = {}
@@ -28,8 +28,8 @@ for ev in prof.events():
     if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or ev.cpu_children and any(c.name.startswith("aten::") and c.device_time_total > 0 for c in ev.cpu_children):
         continue
     frames = [f for f in (ev.stack or []) if "torch/" not in f and "built-in" not in f and "<frozen" not in f][:4]
-    key = (ev.name, str(ev.input_shapes)[:60] if ev.input_shapes else "", " <- ".join(f.split("/")[-1] for f in frames))
+    key = (ev.name, str(ev.input_shapes)[:70] if ev.input_shapes else "", " <- ".join(f.split("/")[-1] for f in frames))
     r = rows.setdefault(key, [0, 0.0])
     r[0] += 1; r[1] += ev.device_time_total
 for (name, shp, where), (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-    print(f"{name:28s} x{n:3d} {us:8.1f} us  {where}")
+    print(f"{name:14s} x{n:3d} {us:8.1f} us  {shp}  {where}")
